@@ -1,0 +1,377 @@
+/* TEST INFRASTRUCTURE - see balance_oracle.h for scope, provenance and the
+ * "parity unpinned" statement.  Plain C99, FP64, no third-party code.
+ * BC.cpp / BC.hpp citations are relative to /root/reference/quadruped_controller. */
+#include "balance_oracle.h"
+
+#include <math.h>
+#include <string.h>
+
+#define NV 12 /* BC.hpp:157 num_variables_qp_   */
+#define NC 20 /* BC.hpp:158 num_constraints_qp_ */
+#define NE 6  /* BC.hpp:156 num_equations_qp_   */
+
+/* ---------------------------------------------------------------- helpers */
+static void mat3_mul(const double* a, const double* b, double* c) { /* c = a b */
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      double s = 0.0;
+      for (int k = 0; k < 3; k++) s += a[3 * i + k] * b[3 * k + j];
+      c[3 * i + j] = s;
+    }
+}
+static void mat3_mul_bt(const double* a, const double* b, double* c) { /* c = a b' */
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      double s = 0.0;
+      for (int k = 0; k < 3; k++) s += a[3 * i + k] * b[3 * j + k];
+      c[3 * i + j] = s;
+    }
+}
+static void mat3_vec(const double* a, const double* v, double* o) {
+  for (int i = 0; i < 3; i++) o[i] = a[3 * i] * v[0] + a[3 * i + 1] * v[1] + a[3 * i + 2] * v[2];
+}
+
+/* rigid3d.cpp:61-74 */
+static void skew_symmetric(const double* v, double* m) {
+  m[0] = 0.0;   m[1] = -v[2]; m[2] = v[1];
+  m[3] = v[2];  m[4] = 0.0;   m[5] = -v[0];
+  m[6] = -v[1]; m[7] = v[0];  m[8] = 0.0;
+}
+
+/* rigid3d.cpp:177-179 + 198-203: Rotation3d(mat).angleAxisTotal() ->
+ * drake::math::RotationMatrix::ToAngleAxis() -> Eigen::AngleAxisd(matrix):
+ * matrix -> quaternion -> angle/axis (published Eigen 3.3 algorithm restated;
+ * Drake v0.26.0 per README.md:101, not vendored). */
+void oracle_angle_axis_total(const double* m, double* out) {
+  double q[4]; /* x y z w */
+  double t = m[0] + m[4] + m[8];
+  if (t > 0.0) {
+    t = sqrt(t + 1.0);
+    q[3] = 0.5 * t;
+    t = 0.5 / t;
+    q[0] = (m[7] - m[5]) * t;
+    q[1] = (m[2] - m[6]) * t;
+    q[2] = (m[3] - m[1]) * t;
+  } else {
+    int i = 0;
+    if (m[4] > m[0]) i = 1;
+    if (m[8] > m[4 * i]) i = 2;
+    int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = sqrt(m[4 * i] - m[4 * j] - m[4 * k] + 1.0);
+    q[i] = 0.5 * t;
+    t = 0.5 / t;
+    q[3] = (m[3 * k + j] - m[3 * j + k]) * t;
+    q[j] = (m[3 * j + i] + m[3 * i + j]) * t;
+    q[k] = (m[3 * k + i] + m[3 * i + k]) * t;
+  }
+  double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+  if (n != 0.0) {
+    double angle = 2.0 * atan2(n, fabs(q[3]));
+    if (q[3] < 0.0) n = -n;
+    out[0] = q[0] / n * angle;
+    out[1] = q[1] / n * angle;
+    out[2] = q[2] / n * angle;
+  } else { /* angle 0, axis (1,0,0) */
+    out[0] = out[1] = out[2] = 0.0;
+  }
+}
+
+/* ------------------------------------------------------------- assembly */
+void oracle_assemble(const oracle_params* P, const double* Rwb, const double* Rwb_d, const double* x,
+                     const double* xdot, const double* w, const double* x_d, const double* xdot_d,
+                     const double* w_d, const double* feet, const unsigned char* stance, double* H,
+                     double* g, double* C, double* lb, double* ub, double* A_out, double* b_out) {
+  /* frictionConeConstraint(), BC.cpp:274-292 (copied into qp_C_ each tick, :327) */
+  const double mu = P->mu;
+  const double Cf[5][3] = {{1.0, 0.0, -mu}, {0.0, 1.0, -mu}, {0.0, 1.0, mu}, {1.0, 0.0, mu}, {0.0, 0.0, 1.0}};
+  memset(C, 0, sizeof(double) * NC * NV);
+  for (int i = 0; i < 4; i++)
+    for (int r = 0; r < 5; r++)
+      for (int c = 0; c < 3; c++) C[(5 * i + r) * NV + 3 * i + c] = Cf[r][c];
+
+  /* frictionConeBounds(), BC.cpp:294-330 */
+  const double upper = 1000000.0, lower = -1000000.0;
+  const double lbf[5] = {lower, lower, 0.0, 0.0, P->fzmin};
+  const double ubf[5] = {0.0, 0.0, upper, upper, P->fzmax};
+  for (int i = 0; i < 4; i++)
+    for (int r = 0; r < 5; r++) {
+      lb[5 * i + r] = stance[i] ? lbf[r] : 0.0;
+      ub[5 * i + r] = stance[i] ? ubf[r] : 0.0;
+    }
+
+  /* PD law, BC.cpp:126-129 */
+  double xddot_d[3], wdot_d[3];
+  for (int k = 0; k < 3; k++) xddot_d[k] = P->kp_p[k] * (x_d[k] - x[k]) + P->kd_p[k] * (xdot_d[k] - xdot[k]);
+  xddot_d[0] += P->kff[0] * xdot_d[0];
+  xddot_d[1] += P->kff[1] * xdot_d[1];
+  xddot_d[2] += P->kff[2] * P->mass * 9.81;
+
+  /* rotation error + angular PD, BC.cpp:133-139 */
+  double R_error[9], aa[3];
+  mat3_mul_bt(Rwb_d, Rwb, R_error);
+  oracle_angle_axis_total(R_error, aa);
+  for (int k = 0; k < 3; k++) wdot_d[k] = P->kp_w[k] * aa[k] + P->kd_w[k] * (w_d[k] - w[k]);
+  wdot_d[0] += P->kff[3] * w_d[0];
+  wdot_d[1] += P->kff[4] * w_d[1];
+  wdot_d[1] += P->kff[5] * w_d[2]; /* sic: index 1, BC.cpp:139 */
+
+  /* dynamics(), BC.cpp:237-272 (its `x` argument is unused) */
+  double A[NE * NV], b[NE];
+  memset(A, 0, sizeof(A));
+  for (int i = 0; i < 4; i++) {
+    double r[3], sk[9];
+    mat3_vec(Rwb, feet + 3 * i, r); /* :244-248 */
+    skew_symmetric(r, sk);
+    for (int k = 0; k < 3; k++) {
+      A[k * NV + 3 * i + k] = 1.0; /* :254-257 */
+      for (int c = 0; c < 3; c++) A[(3 + k) * NV + 3 * i + c] = sk[3 * k + c]; /* :259-262 */
+    }
+  }
+  double RI[9], Iw[9];
+  mat3_mul(Rwb, P->Ib, RI);
+  mat3_mul_bt(RI, Rwb, Iw); /* :251 */
+  const double grav[3] = {0.0, 0.0, -9.81}; /* BC.cpp:76 */
+  for (int k = 0; k < 3; k++) b[k] = P->mass * (xddot_d[k] + grav[k]); /* :265 */
+  double Iwd[3], Iww[3];
+  mat3_vec(Iw, wdot_d, Iwd);
+  mat3_vec(Iw, w_d, Iww);
+  b[3] = Iwd[0] + (w_d[1] * Iww[2] - w_d[2] * Iww[1]); /* :269 */
+  b[4] = Iwd[1] + (w_d[2] * Iww[0] - w_d[0] * Iww[2]);
+  b[5] = Iwd[2] + (w_d[0] * Iww[1] - w_d[1] * Iww[0]);
+
+  /* Q = 2(A'SA + W), c = -2 A'S b, BC.cpp:152-153 */
+  double SA[NE * NV], Sb[NE];
+  for (int i = 0; i < NE; i++) {
+    for (int j = 0; j < NV; j++) {
+      double s = 0.0;
+      for (int k = 0; k < NE; k++) s += P->S[i * NE + k] * A[k * NV + j];
+      SA[i * NV + j] = s;
+    }
+    double s = 0.0;
+    for (int k = 0; k < NE; k++) s += P->S[i * NE + k] * b[k];
+    Sb[i] = s;
+  }
+  for (int i = 0; i < NV; i++) {
+    for (int j = 0; j < NV; j++) {
+      double s = 0.0;
+      for (int k = 0; k < NE; k++) s += A[k * NV + i] * SA[k * NV + j];
+      H[i * NV + j] = 2.0 * (s + P->W[i * NV + j]);
+    }
+    double s = 0.0;
+    for (int k = 0; k < NE; k++) s += A[k * NV + i] * Sb[k];
+    g[i] = -2.0 * s;
+  }
+  if (A_out) memcpy(A_out, A, sizeof(A));
+  if (b_out) memcpy(b_out, b, sizeof(b));
+}
+
+/* --------------------------------------------- dense primal active set QP */
+#define KMAX (NV + NV)
+
+/* Gaussian elimination with partial pivoting, n<=KMAX, in place. 0 on success. */
+static int lin_solve(double* M, double* rhs, int n) {
+  for (int c = 0; c < n; c++) {
+    int p = c;
+    double best = fabs(M[c * KMAX + c]);
+    for (int r = c + 1; r < n; r++)
+      if (fabs(M[r * KMAX + c]) > best) { best = fabs(M[r * KMAX + c]); p = r; }
+    if (best < 1e-300) return 1;
+    if (p != c) {
+      for (int k = 0; k < n; k++) { double t = M[c * KMAX + k]; M[c * KMAX + k] = M[p * KMAX + k]; M[p * KMAX + k] = t; }
+      double t = rhs[c]; rhs[c] = rhs[p]; rhs[p] = t;
+    }
+    for (int r = c + 1; r < n; r++) {
+      double m = M[r * KMAX + c] / M[c * KMAX + c];
+      if (m == 0.0) continue;
+      for (int k = c; k < n; k++) M[r * KMAX + k] -= m * M[c * KMAX + k];
+      rhs[r] -= m * rhs[c];
+    }
+  }
+  for (int r = n - 1; r >= 0; r--) {
+    double s = rhs[r];
+    for (int k = r + 1; k < n; k++) s -= M[r * KMAX + k] * rhs[k];
+    rhs[r] = s / M[r * KMAX + r];
+  }
+  return 0;
+}
+
+/* is row `a` linearly independent of the rows listed in idx[0..m)? */
+static int independent(const double* C, const int* idx, int m, const double* a) {
+  double basis[NV][NV];
+  int nb = 0;
+  for (int t = 0; t <= m; t++) {
+    double v[NV];
+    const double* src = (t < m) ? C + idx[t] * NV : a;
+    double n0 = 0.0;
+    for (int k = 0; k < NV; k++) { v[k] = src[k]; n0 += v[k] * v[k]; }
+    for (int pass = 0; pass < 2; pass++)
+      for (int q = 0; q < nb; q++) {
+        double d = 0.0;
+        for (int k = 0; k < NV; k++) d += basis[q][k] * v[k];
+        for (int k = 0; k < NV; k++) v[k] -= d * basis[q][k];
+      }
+    double n1 = 0.0;
+    for (int k = 0; k < NV; k++) n1 += v[k] * v[k];
+    int indep = n1 > 1e-20 * (n0 > 0 ? n0 : 1.0);
+    if (t == m) return indep;
+    if (indep && nb < NV) {
+      double s = 1.0 / sqrt(n1);
+      for (int k = 0; k < NV; k++) basis[nb][k] = v[k] * s;
+      nb++;
+    }
+  }
+  return 0;
+}
+
+int oracle_qp_solve(const double* H, const double* g, const double* C, const double* lb,
+                    const double* ub, int max_iter, double* f, double* lam_out, int* iters_out) {
+  /* Feasible start: the reference's bounds always admit f_i = (0,0,lb of the
+   * fz row) per foot (BC.cpp:300-301: lbf[4]=fzmin; swing rows are all 0). */
+  for (int k = 0; k < NV; k++) f[k] = 0.0;
+  for (int i = 0; i < 4; i++) f[3 * i + 2] = lb[5 * i + 4];
+  int ws[NC];      /* 0 free, +1 at ub, -1 at lb, 2 equality, 3 redundant equality */
+  int idx[NC], m = 0;
+  const double ftol = 1e-9;
+  for (int r = 0; r < NC; r++) {
+    double cf = 0.0;
+    for (int k = 0; k < NV; k++) cf += C[r * NV + k] * f[k];
+    if (cf > ub[r] + ftol * (1 + fabs(ub[r])) || cf < lb[r] - ftol * (1 + fabs(lb[r]))) return ORACLE_INFEASIBLE;
+    ws[r] = 0;
+  }
+  for (int pass = 0; pass < 2; pass++) /* equalities first, then rows active at f */
+    for (int r = 0; r < NC; r++) {
+      if (ws[r]) continue;
+      double cf = 0.0;
+      for (int k = 0; k < NV; k++) cf += C[r * NV + k] * f[k];
+      int kind = 0;
+      if (pass == 0 && lb[r] == ub[r]) kind = 2;
+      if (pass == 1 && lb[r] != ub[r]) {
+        if (fabs(cf - lb[r]) <= 1e-12 * (1 + fabs(lb[r]))) kind = -1;
+        else if (fabs(cf - ub[r]) <= 1e-12 * (1 + fabs(ub[r]))) kind = 1;
+      }
+      if (kind && m < NV && independent(C, idx, m, C + r * NV)) { ws[r] = kind; idx[m++] = r; }
+      else if (kind == 2) ws[r] = 3; /* equality row implied by earlier equality rows: satisfied
+                                        on the whole working manifold, never blocks, no multiplier */
+    }
+
+  double lam[NC];
+  int it;
+  for (it = 0; it < max_iter; it++) {
+    /* KKT system of the equality-constrained subproblem */
+    double M[KMAX * KMAX], rhs[KMAX];
+    int n = NV + m;
+    memset(M, 0, sizeof(M));
+    for (int i = 0; i < NV; i++) {
+      for (int j = 0; j < NV; j++) M[i * KMAX + j] = H[i * NV + j];
+      rhs[i] = -g[i];
+    }
+    for (int t = 0; t < m; t++) {
+      int r = idx[t];
+      for (int k = 0; k < NV; k++) { M[(NV + t) * KMAX + k] = C[r * NV + k]; M[k * KMAX + NV + t] = C[r * NV + k]; }
+      rhs[NV + t] = (ws[r] == -1) ? lb[r] : ub[r];
+    }
+    if (lin_solve(M, rhs, n)) return ORACLE_NOT_PD;
+    double d[NV];
+    for (int k = 0; k < NV; k++) d[k] = rhs[k] - f[k];
+    /* ratio test over rows outside the working set */
+    double alpha = 1.0;
+    int block = -1, bside = 0;
+    for (int r = 0; r < NC; r++) {
+      if (ws[r]) continue;
+      double cd = 0.0, cf = 0.0;
+      for (int k = 0; k < NV; k++) { cd += C[r * NV + k] * d[k]; cf += C[r * NV + k] * f[k]; }
+      if (cd > 1e-13) {
+        double a = (ub[r] - cf) / cd;
+        if (a < 0) a = 0;
+        if (a < alpha) { alpha = a; block = r; bside = 1; }
+      } else if (cd < -1e-13) {
+        double a = (lb[r] - cf) / cd;
+        if (a < 0) a = 0;
+        if (a < alpha) { alpha = a; block = r; bside = -1; }
+      }
+    }
+    if (block >= 0) {
+      for (int k = 0; k < NV; k++) f[k] += alpha * d[k];
+      if (m < NV && independent(C, idx, m, C + block * NV)) { ws[block] = bside; idx[m++] = block; }
+      continue;
+    }
+    for (int k = 0; k < NV; k++) f[k] = rhs[k];
+    /* multipliers: H f + g + sum lam_t a_t = 0; need lam>=0 at ub, <=0 at lb */
+    int worst = -1;
+    double wv = 0.0, gs = 1.0;
+    for (int k = 0; k < NV; k++) if (fabs(g[k]) > gs) gs = fabs(g[k]);
+    for (int r = 0; r < NC; r++) lam[r] = 0.0;
+    for (int t = 0; t < m; t++) {
+      int r = idx[t];
+      lam[r] = rhs[NV + t];
+      double viol = (ws[r] == 1) ? -lam[r] : (ws[r] == -1 ? lam[r] : 0.0);
+      if (viol > 1e-10 * gs && viol > wv) { wv = viol; worst = t; }
+    }
+    if (worst < 0) {
+      if (lam_out) memcpy(lam_out, lam, sizeof(lam));
+      if (iters_out) *iters_out = it + 1;
+      return ORACLE_OK;
+    }
+    ws[idx[worst]] = 0;
+    for (int t = worst; t + 1 < m; t++) idx[t] = idx[t + 1];
+    m--;
+  }
+  if (iters_out) *iters_out = it;
+  return ORACLE_MAX_ITER;
+}
+
+void oracle_kkt(const double* H, const double* g, const double* C, const double* lb, const double* ub,
+                const double* f, const double* lam, double* stationarity, double* primal, double* dual) {
+  double st = 0.0, pr = 0.0, du = 0.0;
+  for (int i = 0; i < NV; i++) {
+    double s = g[i];
+    for (int j = 0; j < NV; j++) s += H[i * NV + j] * f[j];
+    for (int r = 0; r < NC; r++) s += C[r * NV + i] * lam[r];
+    if (fabs(s) > st) st = fabs(s);
+  }
+  for (int r = 0; r < NC; r++) {
+    double cf = 0.0;
+    for (int k = 0; k < NV; k++) cf += C[r * NV + k] * f[k];
+    if (cf - ub[r] > pr) pr = cf - ub[r];
+    if (lb[r] - cf > pr) pr = lb[r] - cf;
+    if (lb[r] == ub[r]) continue;
+    double comp = (lam[r] > 0) ? lam[r] * fabs(ub[r] - cf) : -lam[r] * fabs(cf - lb[r]);
+    if (comp > du) du = comp;
+  }
+  *stationarity = st; *primal = pr; *dual = du;
+}
+
+/* ------------------------------------------------------- control() */
+int oracle_control(const oracle_params* P, const double* Rwb, const double* Rwb_d, const double* x,
+                   const double* xdot, const double* w, const double* x_d, const double* xdot_d,
+                   const double* w_d, const double* feet, const unsigned char* stance,
+                   double* grf_body, double* f_world, int* iters) {
+  double H[NV * NV], g[NV], C[NC * NV], lb[NC], ub[NC], fw[NV];
+  oracle_assemble(P, Rwb, Rwb_d, x, xdot, w, x_d, xdot_d, w_d, feet, stance, H, g, C, lb, ub, 0, 0);
+  int st = oracle_qp_solve(H, g, C, lb, ub, P->max_iter > 0 ? P->max_iter : 200, fw, 0, iters);
+  for (int k = 0; k < NV; k++) grf_body[k] = 0.0;
+  if (f_world) for (int k = 0; k < NV; k++) f_world[k] = (st == ORACLE_OK) ? fw[k] : 0.0;
+  if (st != ORACLE_OK) return st; /* reference: empty ForceMap, BC.cpp:182-216 */
+  for (int i = 0; i < 4; i++) {
+    if (!stance[i]) continue; /* swing legs omitted, BC.cpp:222 */
+    for (int r = 0; r < 3; r++) /* fb = -Rwb' fw(3i..3i+2), BC.cpp:225 */
+      grf_body[3 * i + r] = -(Rwb[0 + r] * fw[3 * i] + Rwb[3 + r] * fw[3 * i + 1] + Rwb[6 + r] * fw[3 * i + 2]);
+  }
+  return st;
+}
+
+void oracle_control_batch(const oracle_params* P, long n, const double* Rwb, const double* Rwb_d,
+                          const double* x, const double* xdot, const double* w, const double* x_d,
+                          const double* xdot_d, const double* w_d, const double* feet,
+                          const unsigned char* stance, double* grf_body, int* status, int* iters,
+                          int threads) {
+  if (threads < 1) threads = 1;
+#pragma omp parallel for num_threads(threads) schedule(static)
+  for (long i = 0; i < n; i++) {
+    int it = 0;
+    int st = oracle_control(P, Rwb + 9 * i, Rwb_d + 9 * i, x + 3 * i, xdot + 3 * i, w + 3 * i, x_d + 3 * i,
+                            xdot_d + 3 * i, w_d + 3 * i, feet + 12 * i, stance + 4 * i, grf_body + 12 * i, 0, &it);
+    if (status) status[i] = st;
+    if (iters) iters[i] = it;
+  }
+}

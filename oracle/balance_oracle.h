@@ -1,0 +1,76 @@
+/* TEST INFRASTRUCTURE - CPU restatement (plain C, FP64) of the reference hot
+ * path BalanceController::control().  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load this library; the product
+ * (quadruped_control_amd/, include/) never links or calls it.
+ *
+ * PARITY UNPINNED BY REFERENCE FIXTURES: the reference has no tests/golden
+ * vectors for this path and its QP solve lives in qpOASES (README.md:102,
+ * master @326a651), absent from /root/reference and this image together with
+ * Armadillo, Drake/Eigen and ROS.  The assembly is restated line by line from
+ * first-party reference code; the QP (strictly convex => unique minimiser) is
+ * solved by a textbook primal active-set method on the LITERAL data the
+ * reference hands to qpOASES (H, g, 20x12 C, lbA, ubA - two-sided rows,
+ * swing legs as five dependent equality rows), and certified by KKT.
+ *
+ * Citations: BC.cpp = quadruped_controller/src/quadruped_controller/
+ * balance_controller.cpp, BC.hpp = quadruped_controller/include/
+ * quadruped_controller/balance_controller.hpp (under /root/reference).
+ */
+#ifndef BALANCE_ORACLE_H
+#define BALANCE_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Constructor arguments, BC.hpp:85-88.  Matrices row-major. */
+typedef struct oracle_params {
+  double mu, mass, fzmin, fzmax;
+  double Ib[9], S[36], W[144];
+  double kff[6], kp_p[3], kd_p[3], kp_w[3], kd_w[3];
+  int max_iter; /* nWSR_, BC.cpp:85 (200) */
+} oracle_params;
+
+enum { ORACLE_OK = 0, ORACLE_MAX_ITER = 1, ORACLE_INFEASIBLE = 2, ORACLE_NOT_PD = 3 };
+
+/* BC.cpp:107-161: everything handed to qpOASES.  H 12x12, g 12, C 20x12
+ * (row-major, BC.cpp:30-41), lb/ub 20. feet = 4x3 RL,FL,RR,FR body frame,
+ * stance[i] = LegState (1 stance, 0 swing). Also returns A (6x12), b (6). */
+void oracle_assemble(const oracle_params* P, const double* Rwb, const double* Rwb_d, const double* x,
+                     const double* xdot, const double* w, const double* x_d, const double* xdot_d,
+                     const double* w_d, const double* feet, const unsigned char* stance, double* H,
+                     double* g, double* C, double* lb, double* ub, double* A, double* b);
+
+/* rigid3d.cpp:198-203 (Drake RotationMatrix::ToAngleAxis -> Eigen). */
+void oracle_angle_axis_total(const double* R, double* out3);
+
+/* min 1/2 f'Hf + g'f  s.t. lb <= C f <= ub  (BC.cpp:177-210).
+ * lam[20] (optional, may be NULL): signed multipliers, >0 at upper, <0 at lower. */
+int oracle_qp_solve(const double* H, const double* g, const double* C, const double* lb,
+                    const double* ub, int max_iter, double* f, double* lam, int* iters);
+
+/* KKT residuals of (f, lam): stationarity |Hf+g+C'lam|_inf, primal bound
+ * violation, dual sign/complementarity violation. */
+void oracle_kkt(const double* H, const double* g, const double* C, const double* lb, const double* ub,
+                const double* f, const double* lam, double* stationarity, double* primal, double* dual);
+
+/* control() end to end, BC.cpp:98-235.  grf_body[12]: stance legs
+ * -Rwb' f_world (BC.cpp:218-232), swing legs 0 (the reference omits them
+ * from the map).  Failure -> status != 0 and all-zero forces (the reference
+ * returns an empty map, BC.cpp:182-216). */
+int oracle_control(const oracle_params* P, const double* Rwb, const double* Rwb_d, const double* x,
+                   const double* xdot, const double* w, const double* x_d, const double* xdot_d,
+                   const double* w_d, const double* feet, const unsigned char* stance,
+                   double* grf_body, double* f_world, int* iters);
+
+/* n robots, arrays as in include/qc_balance.h (host memory). threads<=1: serial. */
+void oracle_control_batch(const oracle_params* P, long n, const double* Rwb, const double* Rwb_d,
+                          const double* x, const double* xdot, const double* w, const double* x_d,
+                          const double* xdot_d, const double* w_d, const double* feet,
+                          const unsigned char* stance, double* grf_body, int* status, int* iters,
+                          int threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

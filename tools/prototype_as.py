@@ -1,0 +1,132 @@
+"""Design prototype: per-QP primal active set on cube states with optional
+'clamped trial' acceleration. Counts EQP solves. Development tool only."""
+import sys, os
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+from oracle import numpy_restatement as R
+from quadruped_control_amd import workloads as W
+from tools.prototype_solver import assemble_batch
+
+
+class QP:
+    def __init__(s, Q, c, stance, mu, fzmin, fzmax):
+        s.Q, s.c, s.st, s.mu, s.lo, s.hi = Q, c, np.asarray(stance).astype(bool), mu, fzmin, fzmax
+
+    def phi(s, f):
+        return 0.5 * f @ s.Q @ f + s.c @ f
+
+    def eqp(s, S):
+        sx, sy, sz = S
+        T = np.zeros((12, 12)); p = np.zeros(12); D = np.zeros(12)
+        for i in range(4):
+            if not s.st[i]:
+                continue
+            X, Y, Z = 3 * i, 3 * i + 1, 3 * i + 2
+            ax, ay, az = float(sx[i] == 0), float(sy[i] == 0), float(sz[i] == 0)
+            fzfix = 0.0 if sz[i] == 0 else (s.hi if sz[i] > 0 else s.lo)
+            T[X, X] = ax; T[Y, Y] = ay; T[Z, Z] = az
+            T[X, Z] = s.mu * sx[i] * az; T[Y, Z] = s.mu * sy[i] * az
+            p[X] = s.mu * sx[i] * fzfix; p[Y] = s.mu * sy[i] * fzfix; p[Z] = fzfix
+            D[X], D[Y], D[Z] = ax, ay, az
+        H = T.T @ s.Q @ T + np.diag(1 - D)
+        y = np.linalg.solve(H, -T.T @ (s.Q @ p + s.c))
+        f = T @ y + p
+        g = s.Q @ f + s.c
+        lx = -sx * g[0::3]; ly = -sy * g[1::3]; lz = sz * (-g[2::3] + s.mu * (lx + ly))
+        return f, lx, ly, lz
+
+    def clamp(s, f):
+        f = f.copy()
+        S = [np.zeros(4, int), np.zeros(4, int), np.zeros(4, int)]
+        for i in range(4):
+            if not s.st[i]:
+                f[3 * i:3 * i + 3] = 0; continue
+            fz = f[3 * i + 2]
+            if fz >= s.hi: fz = s.hi; S[2][i] = 1
+            elif fz <= s.lo: fz = s.lo; S[2][i] = -1
+            f[3 * i + 2] = fz
+            for a in (0, 1):
+                v = f[3 * i + a]
+                if v >= s.mu * fz: v = s.mu * fz; S[a][i] = 1
+                elif v <= -s.mu * fz: v = -s.mu * fz; S[a][i] = -1
+                f[3 * i + a] = v
+        return f, S
+
+    def ratio(s, f, d, S):
+        """largest alpha in [0,1] keeping feasibility; returns alpha, (axis, foot, sign)"""
+        best, who = 1.0, None
+        for i in range(4):
+            if not s.st[i]:
+                continue
+            fx, fy, fz = f[3 * i:3 * i + 3]; dx, dy, dz = d[3 * i:3 * i + 3]
+            cands = []
+            if S[2][i] == 0:
+                cands += [(2, 1, dz, s.hi - fz), (2, -1, -dz, fz - s.lo)]
+            for a, (v, dv) in enumerate(((fx, dx), (fy, dy))):
+                if S[a][i] == 0:
+                    cands += [(a, 1, dv - s.mu * dz, s.mu * fz - v), (a, -1, -dv - s.mu * dz, s.mu * fz + v)]
+            for axis, sign, nd, slack in cands:
+                if nd > 1e-14:
+                    al = max(slack, 0.0) / nd
+                    if al < best:
+                        best, who = al, (axis, i, sign)
+        return best, who
+
+
+def solve(qp, mode="plain", start="clamp_u", maxit=200, tol=1e-9):
+    nsolve = 0
+    S0 = [np.zeros(4, int), np.zeros(4, int), np.zeros(4, int)]
+    fu, *_ = qp.eqp(S0); nsolve += 1
+    f, S = qp.clamp(fu)
+    if np.allclose(f, fu, atol=1e-12):
+        return f, nsolve, S
+    if start == "interior":
+        f = np.zeros(12); S = S0
+        for i in range(4):
+            if qp.st[i]: f[3 * i + 2] = qp.lo; S[2][i] = -1
+    gs = 1 + np.max(np.abs(qp.c))
+    for it in range(maxit):
+        fh, lx, ly, lz = qp.eqp(S); nsolve += 1
+        d = fh - f
+        if mode == "trial":
+            ft, St = qp.clamp(fh)
+            if np.max(np.abs(ft - fh)) > 1e-12 and qp.phi(ft) < qp.phi(f) - 1e-12 * abs(qp.phi(f)):
+                f, S = ft, St
+                continue
+        al, who = qp.ratio(f, d, S)
+        if al < 1.0:
+            f = f + al * d
+            S[who[0]][who[1]] = who[2]
+            continue
+        f = fh
+        lam = np.stack([np.where(S[0] != 0, lx, np.inf), np.where(S[1] != 0, ly, np.inf), np.where(S[2] != 0, lz, np.inf)])
+        k = np.unravel_index(np.argmin(lam), lam.shape)
+        if lam[k] >= -tol * gs:
+            return f, nsolve, S
+        if mode == "trial":
+            # release ALL negative multipliers at once
+            for a in range(3):
+                S[a][lam[a] < -tol * gs] = 0
+        else:
+            S[k[0]][k[1]] = 0
+    return f, nsolve, S
+
+
+if __name__ == "__main__":
+    cfg = int(sys.argv[1]); n = int(sys.argv[2]); mode = sys.argv[3]; start = sys.argv[4] if len(sys.argv) > 4 else "clamp_u"
+    P = R.cheetah_params(mu=0.6)
+    B = W.config2(n) if cfg == 2 else W.config3(n)
+    Q, c = assemble_batch(P, B)
+    C = R.friction_cone_constraint(P["mu"])
+    ns = []; worst = 0
+    for i in range(n):
+        qp = QP(Q[i], c[i], B["stance"][i], P["mu"], P["fzmin"], P["fzmax"])
+        f, k, S = solve(qp, mode, start)
+        ns.append(k)
+        if i % 8 == 0:
+            lb, ub = R.friction_cone_bounds(B["stance"][i], P["fzmin"], P["fzmax"])
+            ft = R.solve_qp_ldp(Q[i], c[i], C, lb, ub)
+            worst = max(worst, np.max(np.abs(f - ft)) / max(1, np.max(np.abs(ft))))
+    ns = np.array(ns)
+    print(mode, start, "EQP solves: mean %.2f max %d" % (ns.mean(), ns.max()), "hist", np.bincount(ns))
+    print("worst rel err", worst, " per-64 max mean", ns[: n // 64 * 64].reshape(-1, 64).max(1).mean())

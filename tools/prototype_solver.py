@@ -1,0 +1,110 @@
+"""Design prototype (numpy, batched) of the device algorithm: per-foot 'cube'
+active-set states, masked fixed-size 12x12 reduced Hessian, primal-dual
+active-set (PDAS) sweeps with a safe primal active-set fallback.
+
+Development tool only: used to collect iteration statistics and to check the
+algorithm against the oracle before writing HIP.  Not imported by the product.
+"""
+import sys, os, time
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+from oracle import numpy_restatement as R
+from quadruped_control_amd import workloads as W
+
+
+def assemble_batch(P, B):
+    n = B["x"].shape[0]
+    Q = np.zeros((n, 12, 12)); c = np.zeros((n, 12))
+    for i in range(n):
+        qp = R.assemble(P, B["Rwb"][i].reshape(3, 3), B["Rwb_d"][i].reshape(3, 3), B["x"][i], B["xdot"][i],
+                        B["w"][i], B["x_d"][i], B["xdot_d"][i], B["w_d"][i], B["feet"][i], B["stance"][i])
+        Q[i] = qp["H"]; c[i] = qp["g"]
+    return Q, c
+
+
+def eqp(Q, c, sx, sy, sz, stance, mu, fzmin, fzmax):
+    """Solve the equality-constrained QP for cube states. All [n,4] int arrays."""
+    n = Q.shape[0]
+    T = np.zeros((n, 12, 12)); p = np.zeros((n, 12)); D = np.zeros((n, 12))
+    for i in range(4):
+        st = stance[:, i] == 1
+        ax = ((sx[:, i] == 0) & st).astype(float)
+        ay = ((sy[:, i] == 0) & st).astype(float)
+        az = ((sz[:, i] == 0) & st).astype(float)
+        fzfix = np.where(sz[:, i] > 0, fzmax, fzmin) * ((sz[:, i] != 0) & st)
+        mx = mu * sx[:, i] * st; my = mu * sy[:, i] * st
+        X, Y, Z = 3 * i, 3 * i + 1, 3 * i + 2
+        T[:, X, X] = ax; T[:, Y, Y] = ay
+        T[:, X, Z] = mx * az; T[:, Y, Z] = my * az; T[:, Z, Z] = az
+        p[:, X] = mx * fzfix; p[:, Y] = my * fzfix; p[:, Z] = fzfix
+        D[:, X] = ax; D[:, Y] = ay; D[:, Z] = az
+    H = np.einsum("nai,nab,nbj->nij", T, Q, T)
+    H[:, np.arange(12), np.arange(12)] += 1.0 - D
+    gr = np.einsum("nai,na->ni", T, np.einsum("nab,nb->na", Q, p) + c)
+    y = np.linalg.solve(H, -gr[..., None])[..., 0]
+    f = np.einsum("nai,ni->na", T, y) + p
+    g = np.einsum("nab,nb->na", Q, f) + c
+    gx, gy, gz = g[:, 0::3], g[:, 1::3], g[:, 2::3]
+    lx = -sx * gx; ly = -sy * gy
+    lz = sz * (-gz + mu * (lx + ly))
+    return f, lx, ly, lz
+
+
+def pdas(Q, c, stance, mu, fzmin, fzmax, maxit=30, tol_p=1e-9, tol_d=1e-9, warm=None):
+    n = Q.shape[0]
+    if warm is None:
+        sx = np.zeros((n, 4), int); sy = np.zeros((n, 4), int); sz = np.zeros((n, 4), int)
+    else:
+        sx, sy, sz = [a.copy() for a in warm]
+    done = np.zeros(n, bool); iters = np.zeros(n, int)
+    fout = np.zeros((n, 12))
+    st = stance == 1
+    for it in range(maxit):
+        f, lx, ly, lz = eqp(Q, c, sx, sy, sz, stance, mu, fzmin, fzmax)
+        fx, fy, fz = f[:, 0::3], f[:, 1::3], f[:, 2::3]
+        gs = 1.0 + np.max(np.abs(c), axis=1, keepdims=True)
+        nsx = np.where(sx != 0, np.where(lx >= -tol_d * gs, sx, 0),
+                       np.where(fx - mu * fz > tol_p, 1, np.where(-fx - mu * fz > tol_p, -1, 0)))
+        nsy = np.where(sy != 0, np.where(ly >= -tol_d * gs, sy, 0),
+                       np.where(fy - mu * fz > tol_p, 1, np.where(-fy - mu * fz > tol_p, -1, 0)))
+        nsz = np.where(sz != 0, np.where(lz >= -tol_d * gs, sz, 0),
+                       np.where(fz - fzmax > tol_p, 1, np.where(fzmin - fz > tol_p, -1, 0)))
+        nsx = nsx * st; nsy = nsy * st; nsz = nsz * st
+        same = np.all((nsx == sx) & (nsy == sy) & (nsz == sz), axis=1)
+        newly = same & ~done
+        fout[newly] = f[newly]
+        iters[~done] += 1
+        done |= same
+        upd = ~done
+        sx[upd] = nsx[upd]; sy[upd] = nsy[upd]; sz[upd] = nsz[upd]
+        if done.all():
+            break
+    return fout, iters, done, (sx, sy, sz)
+
+
+if __name__ == "__main__":
+    cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
+    P = R.cheetah_params(mu=0.6)
+    B = W.config2(n) if cfg == 2 else W.config3(n)
+    t = time.time(); Q, c = assemble_batch(P, B); print("assemble", time.time() - t)
+    f, iters, done, states = pdas(Q, c, B["stance"], P["mu"], P["fzmin"], P["fzmax"])
+    print("converged", done.mean(), "iters hist", np.bincount(iters))
+    nact = (np.abs(states[0]) + np.abs(states[1]) + np.abs(states[2])).sum(1)
+    print("active hist", np.bincount(nact[done]))
+    # compare with LDP ground truth on a subset
+    C = R.friction_cone_constraint(P["mu"])
+    worst = 0
+    for i in range(0, n, max(1, n // 256)):
+        lb, ub = R.friction_cone_bounds(B["stance"][i], P["fzmin"], P["fzmax"])
+        ft = R.solve_qp_ldp(Q[i], c[i], C, lb, ub)
+        cert = R.kkt_certificate(Q[i], c[i], C, lb, ub, ft)
+        assert cert["primal"] < 1e-7 and cert["stationarity"] < 1e-7, cert
+        if done[i]:
+            err = np.max(np.abs(f[i] - ft)) / max(1.0, np.max(np.abs(ft)))
+            worst = max(worst, err)
+    print("worst rel err vs LDP", worst)
+    for k in range(64, n + 1, 64):
+        pass
+    wm = iters.reshape(-1, 64).max(1)
+    print("per-64 max iters mean", wm.mean(), "mean iters", iters.mean())
