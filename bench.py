@@ -1,0 +1,222 @@
+#!/usr/bin/env python
+"""Headline benchmark: friction-cone QPs/sec of the batched balance controller.
+
+  python bench.py --gpus N --steps K --warmup W [--config 2|3|4|5] [--n ROBOTS]
+
+A "step" is one pass of the hot path (one qc_control_batch launch) over one
+batch of synthetic robots that is already resident in HBM.  Default workload =
+BASELINE.json configs[1]: 4096 randomised COM poses/velocities, all four feet
+in contact, mu = 0.6 (SURVEY.md 8d "config 2").  With N > 1 (launched by
+torch.distributed.run, one rank per GPU) every rank owns its own shard of the
+batch axis (weak scaling: `n` robots per GPU); the path has no data exchange,
+RCCL is used only for the barrier and to reduce the timing / solved counters.
+
+Prints ONE JSON line on rank 0 (see the task contract): value = robots solved
+per second over all ranks; roofline = algorithmic bytes (488 B per robot:
+388 B read + 100 B written) / average kernel time measured with
+HIP events on the launch stream; cpu_baseline = the C oracle (a port, not
+qpOASES) timed on the host cores on the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+BYTES_PER_ROBOT_COLD = 488   # 48 f64 + 4 B stance read; 12 f64 + 4 B status written
+BYTES_PER_ROBOT_WARM = 496   # + 4 B warm word read + 4 B active-set word written
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
+
+CONFIG_N = {2: 4096, 3: 65536, 4: 262144, 5: 262144}  # robots per GPU
+CONFIG_DESC = {
+    2: "config2: batch of {n} randomised COM poses/velocities per GPU, all 4 feet in contact, mu=0.6 pyramid cone, cold start",
+    3: "config3: batch of {n} per GPU, mixed 2/3/4-foot contact states from trot/walk gait schedules, cold start",
+    4: "config4: batch of {n} per GPU, tick 1 warm-started from tick 0's active set (dt=1/300 s)",
+    5: "config5: 2,097,152-robot batch (config-3 distribution) sharded contiguously, {n} per GPU",
+}
+
+
+def make_batch(cfg, n, start):
+    from quadruped_control_amd import workloads as W
+
+    if cfg == 2:
+        return W.config2(n, start=start), None
+    if cfg == 3:
+        return W.config3(n, start=start), None
+    if cfg == 4:
+        t0, t1 = W.config4(n, start=start)
+        return t1, t0
+    return W.config5(n, start=start), None
+
+
+def time_steps(ctl, dev_batch, warm, out, steps, warmup, dist=None):
+    """W untimed steps, then K timed steps bracketed by barrier + synchronize.
+    Returns (wall seconds for K steps, HIP-event seconds for K steps)."""
+    import torch
+
+    for _ in range(warmup):
+        ctl.control_batch(dev_batch, warm=warm, out=out)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()  # torch's current stream == the stream control_batch launches on
+    for _ in range(steps):
+        ctl.control_batch(dev_batch, warm=warm, out=out)
+    ev1.record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    return wall, ev0.elapsed_time(ev1) * 1e-3
+
+
+def run_config(ctl, q, cfg, n, start, steps, warmup, dist=None, device=0):
+    import torch
+
+    batch, prev = make_batch(cfg, n, start)
+    dev_batch = q.to_device(batch, device)
+    warm = None
+    if prev is not None:  # config 4: tick 0 (cold) produces the warm-start words for tick 1
+        o0 = ctl.control_batch(q.to_device(prev, device), want_active_set=True)
+        torch.cuda.synchronize()
+        warm = o0["active_set"]
+    out = {"grf_body": torch.empty((n, 12), dtype=torch.float64, device=f"cuda:{device}"),
+           "status": torch.empty((n,), dtype=torch.int32, device=f"cuda:{device}")}
+    if warm is not None:
+        out["active_set"] = torch.empty((n,), dtype=torch.int32, device=f"cuda:{device}")
+    wall, evs = time_steps(ctl, dev_batch, warm, out, steps, warmup, dist)
+    solved = int((out["status"] == 0).sum().item())
+    return dict(wall=wall, event_s=evs, solved=solved, n=n, batch=batch, warm=warm is not None)
+
+
+def cpu_baseline(P, batch, budget_s=4.0):
+    """C oracle (oracle/balance_oracle.c: a port of the reference path, NOT
+    qpOASES) on the host cores over the same robots; bounded to a few seconds
+    of wall time (~10-30 s of CPU work on >= 4 threads)."""
+    from oracle import c_oracle
+
+    n_all = batch["x"].shape[0]
+    n = min(n_all, 4096)
+    sample = {k: v[:n] for k, v in batch.items()}
+    threads = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    c_oracle.control_batch(P, {k: v[:64] for k, v in sample.items()}, threads=threads)  # warm-up / thread pool
+    t0 = time.perf_counter()
+    c_oracle.control_batch(P, {k: v[:512] for k, v in sample.items()}, threads=1)
+    one = 512 / (time.perf_counter() - t0)
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        c_oracle.control_batch(P, sample, threads=threads)
+        reps += 1
+        if time.perf_counter() - t0 >= budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": reps * n / dt, "unit": "QPs/s", "cores": threads, "kind": "port",
+            "sample": f"first {n} robots of the benchmark batch x {reps} repetitions, {threads} OpenMP threads, "
+                      f"{dt:.1f} s wall; C restatement (textbook primal active set), not qpOASES",
+            "single_thread_value": one}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5])
+    ap.add_argument("--n", type=int, default=0, help="robots per GPU (default: the config's size)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the informational runs of the other configs")
+    args = ap.parse_args()
+
+    import torch
+
+    import quadruped_control_amd as q
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist = dist_mod
+    device = local_rank if world > 1 else 0
+    torch.cuda.set_device(device)
+
+    P = q.cheetah_params(mu=0.6)
+    ctl = q.BalanceController.from_params(P, device=device)
+    cfg = args.config
+    n = args.n or CONFIG_N[cfg]
+    res = run_config(ctl, q, cfg, n, rank * n, args.steps, args.warmup, dist, device)
+
+    wall, solved_total = res["wall"], res["solved"]
+    if dist is not None:
+        t = torch.tensor([wall], dtype=torch.float64, device=f"cuda:{device}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)  # max over ranks
+        s = torch.tensor([res["solved"]], dtype=torch.int64, device=f"cuda:{device}")
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+        wall, solved_total = float(t.item()), int(s.item())
+
+    if rank == 0:
+        total_robots = n * world
+        bytes_per = BYTES_PER_ROBOT_WARM if res["warm"] else BYTES_PER_ROBOT_COLD
+        kernel_s = res["event_s"] / args.steps
+        achieved = bytes_per * n / kernel_s / 1e9
+        line = {
+            "metric": "friction-cone QPs/sec (12 vars, 4-foot stance) at 1/2/4/8 MI355X",
+            "value": total_robots * args.steps / wall,
+            "unit": "QPs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": wall / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": CONFIG_DESC[cfg].format(n=n), "robots_per_gpu": n, "global_batch": total_robots,
+                       "kernel": ctl.kernel_name, "parallelism": f"batch-shard x{world} (no data-path collective)"},
+            "solved_fraction": solved_total / total_robots,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "qc::balance_kernel", "bytes_per_launch": bytes_per * n,
+                         "avg_kernel_us": kernel_s * 1e6,
+                         "note": "latency/FP64-VALU bound active-set solve; traffic from the PMC pass is in profiles/"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(P, res["batch"])
+        if world == 1 and not args.no_sweep:
+            other = {}
+            for c in (2, 3, 4):
+                if c == cfg:
+                    continue
+                r = run_config(ctl, q, c, CONFIG_N[c], 0, max(5, min(args.steps, 50)), 3, None, device)
+                k = max(5, min(args.steps, 50))
+                other[f"config{c}"] = {"robots": CONFIG_N[c], "QPs_per_s": CONFIG_N[c] * k / r["wall"],
+                                       "solved_fraction": r["solved"] / CONFIG_N[c],
+                                       "hbm_GBs": (BYTES_PER_ROBOT_WARM if r["warm"] else BYTES_PER_ROBOT_COLD) * CONFIG_N[c] * k / r["event_s"] / 1e9}
+            line["other_configs"] = other
+        print(json.dumps(line), flush=True)
+
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

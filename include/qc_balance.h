@@ -1,0 +1,127 @@
+/* qc_balance.h - C ABI of the MI355X-native batched balance controller.
+ *
+ * Drop-in boundary for ONE path of bostoncleek/quadruped_control:
+ *   quadruped_controller::BalanceController::control()
+ *     quadruped_controller/include/quadruped_controller/balance_controller.hpp:85-107
+ *     quadruped_controller/src/quadruped_controller/balance_controller.cpp:70-330
+ * i.e. PD wrench law -> single-rigid-body Newton-Euler map -> 12-variable
+ * friction-cone QP (solved there by qpOASES SQProblem, balance_controller.cpp:177-210)
+ * -> body-frame ground reaction forces.  One *instance* = one robot tick; the
+ * batch axis is "independent robots".  All arithmetic is FP64, leg order is
+ * RL, FL, RR, FR (commander_node.cpp:61), matrices are row-major.
+ *
+ * Plain C: pointers and sizes only, no C++/torch types, no exceptions.
+ * The library is HIP-only (gfx950); there is no CPU fallback behind this ABI.
+ */
+#ifndef QC_BALANCE_H
+#define QC_BALANCE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QC_ABI_VERSION 1
+
+/* Replaces the constructor arguments of BalanceController
+ * (balance_controller.hpp:85-88; defaults in commander_node.cpp:289-334 and
+ * quadruped_simulation/config/mit_cheetah_config.yaml:66-99). */
+typedef struct qc_params {
+  double mu;       /* friction coefficient                                  */
+  double mass;     /* total mass (kg)                                       */
+  double fzmin;    /* min normal force (N), 0 <= fzmin <= fzmax             */
+  double fzmax;    /* max normal force (N)                                  */
+  double Ib[9];    /* trunk inertia, body frame (3x3)                       */
+  double S[36];    /* SPD weight on the wrench residual (6x6)               */
+  double W[144];   /* SPD weight on the forces (12x12)                      */
+  double kff[6];   /* feed-forward gains                                    */
+  double kp_p[3];  /* COM position Kp                                       */
+  double kd_p[3];  /* COM linear-velocity Kd                                */
+  double kp_w[3];  /* COM orientation Kp                                    */
+  double kd_w[3];  /* COM angular-velocity Kd                               */
+  int32_t max_iter; /* working-set recalculation cap; <=0 -> 200 (nWSR_, balance_controller.cpp:85) */
+  int32_t reserved;
+} qc_params;
+
+/* Replaces the per-call arguments of control() (balance_controller.hpp:104-107),
+ * one row per robot.  DEVICE pointers for qc_control_batch, HOST pointers for
+ * qc_control_batch_host.  8-byte aligned; `stance` may be NULL = make_stance_gait()
+ * (gait.cpp:24-34, the default argument of control()). */
+typedef struct qc_batch_in {
+  const double* Rwb;     /* [n][9]  rotation world<-base                     */
+  const double* Rwb_d;   /* [n][9]  desired rotation                         */
+  const double* x;       /* [n][3]  COM position                             */
+  const double* xdot;    /* [n][3]  COM linear velocity                      */
+  const double* w;       /* [n][3]  COM angular velocity                     */
+  const double* x_d;     /* [n][3]  desired COM position                     */
+  const double* xdot_d;  /* [n][3]  desired COM linear velocity              */
+  const double* w_d;     /* [n][3]  desired COM angular velocity             */
+  const double* feet;    /* [n][4][3] foot positions, body frame (FootholdMap, types.hpp:108) */
+  const uint8_t* stance; /* [n][4]  LegState per leg: 1 stance, 0 swing (GaitMap, types.hpp:91-100) */
+} qc_batch_in;
+
+/* Replaces the returned ForceMap (types.hpp:119; balance_controller.cpp:218-232). */
+typedef struct qc_batch_out {
+  double* grf_body;     /* [n][4][3] = -Rwb^T f_world for stance legs; 0 for swing legs
+                           (the reference omits swing legs from the map); 0 if status != 0 */
+  int32_t* status;      /* [n] qc_status; != 0 is the reference's "empty ForceMap" (balance_controller.cpp:182-216) */
+  uint32_t* active_set; /* [n] optional (may be NULL): optimal working set, feed back as `warm` next tick */
+  int32_t* iterations;  /* [n] optional (may be NULL): working-set recalculations used */
+} qc_batch_out;
+
+typedef enum qc_status {
+  QC_SOLVED = 0,
+  QC_MAX_ITER = 1,   /* RET_MAX_NWSR_REACHED analogue */
+  QC_INFEASIBLE = 2, /* kept for ABI completeness; cannot occur for 0 <= fzmin <= fzmax */
+  QC_NOT_PD = 3      /* Hessian not positive definite / non-finite input (balance_controller.cpp:155-158 only logs) */
+} qc_status;
+
+/* return codes of the entry points */
+#define QC_OK 0
+#define QC_ERR_INVALID (-1) /* bad argument (see qc_last_error)  */
+#define QC_ERR_HIP (-2)     /* HIP runtime error                 */
+#define QC_ERR_NO_DEVICE (-3)
+
+typedef struct qc_handle qc_handle;
+
+/* BalanceController::BalanceController (balance_controller.cpp:70-96).
+ * `device` = HIP device ordinal.  A handle is used by one thread at a time
+ * (like the reference object, whose control() mutates `mutable` members,
+ * balance_controller.hpp:161-176); distinct handles are independent. */
+int qc_create(const qc_params* params, int device, qc_handle** out);
+void qc_destroy(qc_handle* h);
+
+/* control() for n robots, device-resident inputs/outputs, asynchronous on
+ * `stream` (a hipStream_t, NULL = default stream).  `warm` = device array [n]
+ * of active_set words from the previous tick (the qpOASES hotstart analogue,
+ * balance_controller.cpp:191-202) or NULL for a cold start. */
+int qc_control_batch(qc_handle* h, size_t n, const qc_batch_in* in, const uint32_t* warm,
+                     const qc_batch_out* out, void* stream);
+
+/* Same with HOST pointers: stages through handle-owned device buffers and
+ * synchronises before returning. */
+int qc_control_batch_host(qc_handle* h, size_t n, const qc_batch_in* in, const uint32_t* warm,
+                          const qc_batch_out* out);
+
+/* One robot, host arguments laid out exactly like control()'s parameter list;
+ * what the C++ BalanceController adapter (include/qc_balance_controller.hpp) calls. */
+int qc_control(qc_handle* h, const double* Rwb, const double* Rwb_d, const double* x,
+               const double* xdot, const double* w, const double* x_d, const double* xdot_d,
+               const double* w_d, const double* feet, const uint8_t* stance, double* grf_body,
+               int32_t* status);
+
+/* Thread-local message of the last failing call (ROS_ERROR replacement,
+ * balance_controller.cpp:157,184,199,214). */
+const char* qc_last_error(void);
+
+/* Introspection: which device formulation the handle selected
+ * ("diagW-6x6" or "dense-12x12"), and ABI version. */
+const char* qc_kernel_name(const qc_handle* h);
+int qc_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QC_BALANCE_H */

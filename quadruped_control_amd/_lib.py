@@ -1,0 +1,87 @@
+"""ctypes view of libqc_balance.so (C ABI: include/qc_balance.h).
+
+There is NO fallback: if the HIP library is missing or cannot be loaded the
+import of the controller fails loudly.  The .so is built in-tree by
+__graft_entry__.build() (hipcc --offload-arch=gfx950).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libqc_balance.so")
+
+QC_OK = 0
+STATUS_NAMES = {0: "solved", 1: "max_iter", 2: "infeasible", 3: "not_pd"}
+
+
+class QcParams(C.Structure):
+    _fields_ = [("mu", C.c_double), ("mass", C.c_double), ("fzmin", C.c_double), ("fzmax", C.c_double),
+                ("Ib", C.c_double * 9), ("S", C.c_double * 36), ("W", C.c_double * 144),
+                ("kff", C.c_double * 6), ("kp_p", C.c_double * 3), ("kd_p", C.c_double * 3),
+                ("kp_w", C.c_double * 3), ("kd_w", C.c_double * 3),
+                ("max_iter", C.c_int32), ("reserved", C.c_int32)]
+
+
+class QcBatchIn(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in
+                ("Rwb", "Rwb_d", "x", "xdot", "w", "x_d", "xdot_d", "w_d", "feet", "stance")]
+
+
+class QcBatchOut(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("grf_body", "status", "active_set", "iterations")]
+
+
+EXPORTS = ("qc_create", "qc_destroy", "qc_control_batch", "qc_control_batch_host", "qc_control",
+           "qc_last_error", "qc_kernel_name", "qc_abi_version")
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 /
+    # libhsa-runtime64 (same SONAME as /opt/rocm's).  If our library were loaded
+    # first it would pull in /opt/rocm's copy and a later `import torch` would
+    # bring up a second HSA runtime that sees no GPU.  Importing torch first
+    # makes the dynamic loader resolve our NEEDED libamdhip64.so.7 to the copy
+    # torch already mapped.  (A C++ host that never loads torch simply uses
+    # /opt/rocm's runtime.)
+    try:
+        import torch  # noqa: F401
+    except ImportError:  # pragma: no cover - torch is optional plumbing
+        pass
+    lib = C.CDLL(LIB_PATH)
+    for name in EXPORTS:
+        if not hasattr(lib, name):
+            raise ImportError(f"{LIB_PATH} does not export {name}")
+    lib.qc_create.argtypes = [C.POINTER(QcParams), C.c_int, C.POINTER(C.c_void_p)]
+    lib.qc_create.restype = C.c_int
+    lib.qc_destroy.argtypes = [C.c_void_p]
+    lib.qc_destroy.restype = None
+    lib.qc_control_batch.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(QcBatchIn), C.c_void_p,
+                                     C.POINTER(QcBatchOut), C.c_void_p]
+    lib.qc_control_batch.restype = C.c_int
+    lib.qc_control_batch_host.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(QcBatchIn), C.c_void_p,
+                                          C.POINTER(QcBatchOut)]
+    lib.qc_control_batch_host.restype = C.c_int
+    lib.qc_control.argtypes = [C.c_void_p] + [C.c_void_p] * 10 + [C.c_void_p, C.c_void_p]
+    lib.qc_control.restype = C.c_int
+    lib.qc_last_error.restype = C.c_char_p
+    lib.qc_kernel_name.argtypes = [C.c_void_p]
+    lib.qc_kernel_name.restype = C.c_char_p
+    lib.qc_abi_version.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().qc_last_error().decode()

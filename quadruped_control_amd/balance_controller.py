@@ -1,0 +1,193 @@
+"""Host-side mirror of the reference's BalanceController for this path.
+
+Reference interface being mirrored (names, argument order and meaning, error
+behaviour):
+  quadruped_controller/include/quadruped_controller/balance_controller.hpp:85-107
+  quadruped_controller/src/quadruped_controller/balance_controller.cpp:70-235
+  * constructor(mu, mass, fzmin, fzmax, Ib, S, W, kff, kp_p, kd_p, kp_w, kd_w, leg_names)
+  * control(Rwb, Rwb_d, x, xdot, w, x_d, xdot_d, w_d, foot_map, gait_map=make_stance_gait())
+      -> ForceMap {leg: vec3} holding STANCE legs only; EMPTY map on solver
+      failure (balance_controller.cpp:182-216); KeyError (std::out_of_range in
+      the reference) if a leg is missing from foot_map / gait_map.
+plus the batched entry point the GPU exists for, control_batch().
+
+Everything numeric runs in the HIP library behind include/qc_balance.h;
+torch is used only to own device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .gait import LEG_NAMES, LegState, make_stance_gait
+
+_IN_FIELDS = (("Rwb", 9), ("Rwb_d", 9), ("x", 3), ("xdot", 3), ("w", 3), ("x_d", 3), ("xdot_d", 3),
+              ("w_d", 3), ("feet", 12))
+
+
+def _fill(carr, values, n, name):
+    a = np.ascontiguousarray(np.asarray(values, dtype=np.float64).reshape(-1))
+    if a.size != n:
+        raise ValueError(f"{name}: expected {n} values, got {a.size}")
+    carr[:] = a.tolist()
+
+
+class BalanceController:
+    """Reactive optimal force-balance controller (drop-in for the reference class)."""
+
+    def __init__(self, mu, mass, fzmin, fzmax, Ib, S, W, kff, kp_p, kd_p, kp_w, kd_w,
+                 leg_names=LEG_NAMES, *, device=0, max_iter=200):
+        lib = _lib.load()
+        p = _lib.QcParams()
+        p.mu, p.mass, p.fzmin, p.fzmax = float(mu), float(mass), float(fzmin), float(fzmax)
+        _fill(p.Ib, Ib, 9, "Ib"); _fill(p.S, S, 36, "S"); _fill(p.W, W, 144, "W")
+        _fill(p.kff, kff, 6, "kff"); _fill(p.kp_p, kp_p, 3, "kp_p"); _fill(p.kd_p, kd_p, 3, "kd_p")
+        _fill(p.kp_w, kp_w, 3, "kp_w"); _fill(p.kd_w, kd_w, 3, "kd_w")
+        p.max_iter = int(max_iter)
+        self.leg_names = tuple(leg_names)
+        if len(self.leg_names) != 4:
+            raise ValueError("leg_names must hold 4 names (order RL, FL, RR, FR in the reference)")
+        self.device = int(device)
+        self._h = C.c_void_p()
+        self._lib = lib
+        rc = lib.qc_create(C.byref(p), self.device, C.byref(self._h))
+        if rc != _lib.QC_OK:
+            raise RuntimeError(f"qc_create failed ({rc}): {_lib.last_error()}")
+
+    @classmethod
+    def from_params(cls, P, **kw):
+        return cls(P["mu"], P["mass"], P["fzmin"], P["fzmax"], P["Ib"], P["S"], P["W"], P["kff"],
+                   P["kp_p"], P["kd_p"], P["kp_w"], P["kd_w"], **kw)
+
+    @property
+    def kernel_name(self):
+        return self._lib.qc_kernel_name(self._h).decode()
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.qc_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------ single robot
+    def control(self, Rwb, Rwb_d, x, xdot, w, x_d, xdot_d, w_d, foot_map, gait_map=None):
+        """Same contract as the reference's control(); returns {leg_name: np.ndarray(3)}."""
+        if gait_map is None:
+            gait_map = make_stance_gait()
+        feet = np.zeros(12)
+        stance = np.zeros(4, dtype=np.uint8)
+        for i, name in enumerate(self.leg_names):
+            feet[3 * i:3 * i + 3] = np.asarray(foot_map[name], dtype=np.float64).reshape(3)  # KeyError == out_of_range
+            stance[i] = 1 if int(gait_map[name][0]) == int(LegState.stance) else 0
+        args = [np.ascontiguousarray(np.asarray(v, dtype=np.float64).reshape(-1))
+                for v in (Rwb, Rwb_d, x, xdot, w, x_d, xdot_d, w_d)]
+        for a, k in zip(args, (9, 9, 3, 3, 3, 3, 3, 3)):
+            if a.size != k:
+                raise ValueError("control(): argument has the wrong size")
+        grf = np.zeros(12)
+        status = np.zeros(1, dtype=np.int32)
+        ptr = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        rc = self._lib.qc_control(self._h, *[ptr(a) for a in args], ptr(feet), ptr(stance), ptr(grf), ptr(status))
+        if rc != _lib.QC_OK:
+            raise RuntimeError(f"qc_control failed ({rc}): {_lib.last_error()}")
+        force_map = {}
+        if status[0] != 0:
+            return force_map  # reference: ROS_ERROR + empty ForceMap
+        for i, name in enumerate(self.leg_names):
+            if stance[i]:
+                force_map[name] = grf[3 * i:3 * i + 3].copy()
+        return force_map
+
+    # ------------------------------------------------------------------ batches
+    def control_batch(self, batch, warm=None, out=None, want_active_set=False, want_iterations=False, stream=None):
+        """n robots, device-resident.  `batch`: dict of CUDA/HIP torch tensors
+        (float64, contiguous; 'stance' uint8 [n,4] or None) on this controller's
+        device.  Asynchronous on `stream` (default: torch's current stream).
+        Returns dict(grf_body [n,12], status [n] int32, active_set?, iterations?)."""
+        import torch
+
+        n = batch["x"].shape[0]
+        dev = torch.device("cuda", self.device)
+        bi = _lib.QcBatchIn()
+        for name, k in _IN_FIELDS:
+            t = batch[name]
+            if t.dtype != torch.float64 or not t.is_contiguous() or t.device != dev or t.numel() != n * k:
+                raise ValueError(f"{name}: need contiguous float64 [{n},{k}] on {dev}")
+            setattr(bi, name, t.data_ptr())
+        st = batch.get("stance")
+        if st is not None:
+            if st.dtype != torch.uint8 or not st.is_contiguous() or st.numel() != n * 4 or st.device != dev:
+                raise ValueError("stance: need contiguous uint8 [n,4]")
+            bi.stance = st.data_ptr()
+        if out is None:
+            out = {"grf_body": torch.empty((n, 12), dtype=torch.float64, device=dev),
+                   "status": torch.empty((n,), dtype=torch.int32, device=dev)}
+            if want_active_set:
+                out["active_set"] = torch.empty((n,), dtype=torch.int32, device=dev)
+            if want_iterations:
+                out["iterations"] = torch.empty((n,), dtype=torch.int32, device=dev)
+        bo = _lib.QcBatchOut()
+        bo.grf_body = out["grf_body"].data_ptr()
+        bo.status = out["status"].data_ptr()
+        bo.active_set = out["active_set"].data_ptr() if "active_set" in out else None
+        bo.iterations = out["iterations"].data_ptr() if "iterations" in out else None
+        warm_ptr = None
+        if warm is not None:
+            if warm.dtype != torch.int32 or warm.numel() != n or not warm.is_contiguous():
+                raise ValueError("warm: need contiguous int32 [n] (an active_set output)")
+            warm_ptr = warm.data_ptr()
+        s = stream if stream is not None else torch.cuda.current_stream(dev)
+        rc = self._lib.qc_control_batch(self._h, n, C.byref(bi), warm_ptr, C.byref(bo), C.c_void_p(s.cuda_stream))
+        if rc != _lib.QC_OK:
+            raise RuntimeError(f"qc_control_batch failed ({rc}): {_lib.last_error()}")
+        return out
+
+    def control_batch_host(self, batch, warm=None, want_active_set=False, want_iterations=False):
+        """n robots, numpy (host) arrays in and out; PCIe-inclusive convenience path."""
+        n = batch["x"].shape[0]
+        keep = []
+        bi = _lib.QcBatchIn()
+        for name, k in _IN_FIELDS:
+            a = np.ascontiguousarray(batch[name], dtype=np.float64)
+            if a.size != n * k:
+                raise ValueError(f"{name}: expected [{n},{k}]")
+            keep.append(a)
+            setattr(bi, name, a.ctypes.data)
+        st = batch.get("stance")
+        if st is not None:
+            st = np.ascontiguousarray(st, dtype=np.uint8)
+            keep.append(st)
+            bi.stance = st.ctypes.data
+        out = {"grf_body": np.zeros((n, 12)), "status": np.zeros(n, dtype=np.int32)}
+        if want_active_set:
+            out["active_set"] = np.zeros(n, dtype=np.uint32)
+        if want_iterations:
+            out["iterations"] = np.zeros(n, dtype=np.int32)
+        bo = _lib.QcBatchOut()
+        bo.grf_body = out["grf_body"].ctypes.data
+        bo.status = out["status"].ctypes.data
+        bo.active_set = out["active_set"].ctypes.data if want_active_set else None
+        bo.iterations = out["iterations"].ctypes.data if want_iterations else None
+        wp = None
+        if warm is not None:
+            warm = np.ascontiguousarray(warm, dtype=np.uint32)
+            wp = warm.ctypes.data
+        rc = self._lib.qc_control_batch_host(self._h, n, C.byref(bi), wp, C.byref(bo))
+        if rc != _lib.QC_OK:
+            raise RuntimeError(f"qc_control_batch_host failed ({rc}): {_lib.last_error()}")
+        return out
+
+
+def to_device(batch, device=0):
+    """numpy batch (workloads.py) -> dict of torch tensors on cuda:<device>."""
+    import torch
+
+    dev = torch.device("cuda", device)
+    return {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in batch.items()}

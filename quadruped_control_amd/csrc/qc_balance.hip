@@ -1,0 +1,394 @@
+// qc_balance.hip - kernels and C ABI (include/qc_balance.h) of the MI355X-native
+// batched balance controller.  gfx950 only; fails loudly without a HIP device.
+//
+// Replaces BalanceController::control()
+//   quadruped_controller/src/quadruped_controller/balance_controller.cpp:98-330 (BC.cpp)
+// for n independent robots per launch.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "../../include/qc_balance.h"
+#include "qc_device.hpp"
+
+namespace qc {
+
+// ------------------------------------------------------------------ the kernel
+// One lane = one robot.  Primal active-set method on the per-foot cube states:
+//   start   f^ = EQP(S0)  (S0 = no active face, or the warm-start word);
+//           f = clamp(f^); if nothing was clamped f^ is feasible.
+//   iterate f^ = EQP(S);  step f -> f^ until the first blocking face (add it),
+//           or, after a full step, drop the face with the most negative
+//           multiplier; stop when all multipliers are >= 0 (KKT).
+// The QP is strictly convex (W > 0), so the KKT point is THE minimiser qpOASES
+// returns in the reference (BC.cpp:177-210).
+// Per-lane solver state and one working-set recalculation.
+template <class Eqp>
+struct LaneState {
+  const DevParams& P;
+  const Wrench& Wr;
+  const uint32_t stance_mask;
+  Eqp& eqp;
+  Cube& C;
+  double f[12];
+  int status = QC_MAX_ITER;
+  int iters = 0;
+  bool have_f = false, done = false;
+
+  QC_DEV void step() {
+    double fh[12], g[12];
+    iters++;
+    if (!eqp.solve(P, Wr, C, stance_mask, fh, g)) { status = QC_NOT_PD; done = true; return; }
+
+    if (!have_f) {
+      // first point: clamp f^ into the frusta
+      have_f = true;
+      bool changed = false;
+      Cube Cc;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        f[3 * i] = fh[3 * i]; f[3 * i + 1] = fh[3 * i + 1]; f[3 * i + 2] = fh[3 * i + 2];
+        Cc.sx[i] = Cc.sy[i] = Cc.sz[i] = 0;
+        if ((stance_mask >> i) & 1u)
+          changed |= clamp_foot(P.mu, P.fzmin, P.fzmax, f[3 * i], f[3 * i + 1], f[3 * i + 2], Cc.sx[i], Cc.sy[i], Cc.sz[i]);
+      }
+      if (changed) { C = Cc; return; }
+    } else {
+      Ratio best;
+      best.num = 1.0; best.den = 1.0; best.code = -1;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        if (!((stance_mask >> i) & 1u)) continue;
+        const double fx = f[3 * i], fy = f[3 * i + 1], fz = f[3 * i + 2];
+        const double dx = fh[3 * i] - fx, dy = fh[3 * i + 1] - fy, dz = fh[3 * i + 2] - fz;
+        if (C.sz[i] == 0) {
+          ratio_try(best, P.fzmax - fz, dz, i * 8 + 4 + 1);
+          ratio_try(best, fz - P.fzmin, -dz, i * 8 + 4 + 0);
+        }
+        const double m = P.mu * fz, md = P.mu * dz;
+        if (C.sx[i] == 0) {
+          ratio_try(best, m - fx, dx - md, i * 8 + 0 + 1);
+          ratio_try(best, m + fx, -dx - md, i * 8 + 0 + 0);
+        }
+        if (C.sy[i] == 0) {
+          ratio_try(best, m - fy, dy - md, i * 8 + 2 + 1);
+          ratio_try(best, m + fy, -dy - md, i * 8 + 2 + 0);
+        }
+      }
+      if (best.code >= 0) {
+        const double alpha = best.num / best.den;
+#pragma unroll
+        for (int k = 0; k < 12; k++) f[k] = __builtin_fma(alpha, fh[k] - f[k], f[k]);
+        const int foot = best.code >> 3, axis = (best.code >> 1) & 3, sg = (best.code & 1) ? 1 : -1;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          if (i == foot) {
+            if (axis == 0) C.sx[i] = sg;
+            else if (axis == 1) C.sy[i] = sg;
+            else C.sz[i] = sg;
+          }
+        return;
+      }
+    }
+
+    // full step: f = f^; test the multipliers of the active faces
+    double gs = 1.0;
+#pragma unroll
+    for (int k = 0; k < 12; k++) { f[k] = fh[k]; gs = fmax(gs, fabs(g[k])); }
+    double worst = -P.tol_d * gs;
+    int wcode = -1;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      if (!((stance_mask >> i) & 1u)) continue;
+      const double lx = -(double)C.sx[i] * g[3 * i];
+      const double ly = -(double)C.sy[i] * g[3 * i + 1];
+      const double lz = (double)C.sz[i] * (P.mu * (lx + ly) - g[3 * i + 2]);
+      if (C.sz[i] != 0 && lz < worst) { worst = lz; wcode = i * 4 + 2; }
+      if (C.sx[i] != 0 && lx < worst) { worst = lx; wcode = i * 4 + 0; }
+      if (C.sy[i] != 0 && ly < worst) { worst = ly; wcode = i * 4 + 1; }
+    }
+    if (wcode < 0) { status = QC_SOLVED; done = true; return; }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      if (i == (wcode >> 2)) {
+        const int axis = wcode & 3;
+        if (axis == 0) C.sx[i] = 0;
+        else if (axis == 1) C.sy[i] = 0;
+        else C.sz[i] = 0;
+      }
+  }
+};
+
+template <class Eqp>
+__global__ __launch_bounds__(64) void balance_kernel(const DevParams P, const long n, const BatchIn in,
+                                                     const uint32_t* __restrict__ warm, const BatchOut out) {
+  const long gid = (long)blockIdx.x * 64 + threadIdx.x;
+  const bool valid = gid < n;
+  const long idx = valid ? gid : n - 1;  // tail lanes recompute the last robot, never store
+
+  double R[9];
+  Wrench Wr;
+  build_wrench(P, in, idx, R, Wr);
+
+  uint32_t stance_mask = 0xFu;  // make_stance_gait(), gait.cpp:24-34
+  if (in.stance) {
+    const uint32_t sw = *reinterpret_cast<const uint32_t*>(in.stance + 4 * idx);
+    stance_mask = ((sw & 0xFFu) ? 1u : 0u) | ((sw & 0xFF00u) ? 2u : 0u) | ((sw & 0xFF0000u) ? 4u : 0u) | ((sw & 0xFF000000u) ? 8u : 0u);
+  }
+
+  Eqp eqp(P, Wr);
+
+  Cube C;
+#pragma unroll
+  for (int i = 0; i < 4; i++) C.sx[i] = C.sy[i] = C.sz[i] = 0;
+  if (warm) {
+    const uint32_t wv = warm[idx];
+    if (wv & 0x80000000u) decode_states(wv, C);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      if (!((stance_mask >> i) & 1u)) C.sx[i] = C.sy[i] = C.sz[i] = 0;
+  }
+
+  LaneState<Eqp> L{P, Wr, stance_mask, eqp, C};
+#pragma unroll
+  for (int k = 0; k < 12; k++) L.f[k] = 0.0;
+  for (;;) {
+    if (!L.done && L.iters >= P.max_iter) L.done = true;  // status stays QC_MAX_ITER
+    if (__builtin_amdgcn_ballot_w64(!L.done) == 0) break;  // wave-uniform exit
+    if (!L.done) L.step();
+  }
+  const int status = L.status, iters = L.iters;
+  const double(&f)[12] = L.f;
+
+  if (!valid) return;
+  // output transform, BC.cpp:218-232: fb = -Rwb^T fw for stance legs
+  double* o = out.grf_body + 12 * idx;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const bool st = ((stance_mask >> i) & 1u) && status == QC_SOLVED;
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      const double v = -(R[r] * f[3 * i] + R[3 + r] * f[3 * i + 1] + R[6 + r] * f[3 * i + 2]);
+      o[3 * i + r] = st ? v : 0.0;
+    }
+  }
+  out.status[idx] = status;
+  if (out.active_set) out.active_set[idx] = encode_states(C);
+  if (out.iterations) out.iterations[idx] = iters;
+}
+
+struct EqpDiagW {
+  QC_DEV EqpDiagW(const DevParams&, const Wrench&) {}
+  QC_DEV bool solve(const DevParams& P, const Wrench& Wr, const Cube& C, uint32_t stance_mask, double (&f)[12], double (&g)[12]) {
+    return eqp_diagw(P, Wr, C, stance_mask, f, g);
+  }
+};
+
+}  // namespace qc
+
+// =============================================================== host / C ABI
+struct qc_handle {
+  int device;
+  qc::DevParams dp;
+  bool diag_w;
+  // staging buffers for the host-pointer entry points
+  void* stage;
+  size_t stage_bytes;
+  hipStream_t stream;
+};
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define QC_HIP(expr)                                                                      \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess) return fail(QC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+// Cholesky-based inverse of a small SPD matrix (host, once per handle)
+static bool spd_inverse(const double* A, int n, double* inv) {
+  double L[36];
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j <= i; j++) {
+      double s = A[i * n + j];
+      for (int k = 0; k < j; k++) s -= L[i * n + k] * L[j * n + k];
+      if (i == j) {
+        if (!(s > 0.0)) return false;
+        L[i * n + i] = std::sqrt(s);
+      } else {
+        L[i * n + j] = s / L[j * n + j];
+      }
+    }
+  for (int c = 0; c < n; c++) {
+    double y[6], x[6];
+    for (int i = 0; i < n; i++) {
+      double s = (i == c) ? 1.0 : 0.0;
+      for (int k = 0; k < i; k++) s -= L[i * n + k] * y[k];
+      y[i] = s / L[i * n + i];
+    }
+    for (int i = n - 1; i >= 0; i--) {
+      double s = y[i];
+      for (int k = i + 1; k < n; k++) s -= L[k * n + i] * x[k];
+      x[i] = s / L[i * n + i];
+    }
+    for (int i = 0; i < n; i++) inv[i * n + c] = x[i];
+  }
+  return true;
+}
+
+extern "C" {
+
+const char* qc_last_error(void) { return g_err.c_str(); }
+int qc_abi_version(void) { return QC_ABI_VERSION; }
+const char* qc_kernel_name(const qc_handle* h) { return h ? (h->diag_w ? "diagW-6x6" : "dense-12x12") : ""; }
+
+int qc_create(const qc_params* p, int device, qc_handle** out) {
+  if (!p || !out) return fail(QC_ERR_INVALID, "qc_create: null argument");
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(QC_ERR_NO_DEVICE, "qc_create: no HIP device visible (this library has no CPU path)");
+  if (device < 0 || device >= ndev) return fail(QC_ERR_INVALID, "qc_create: device ordinal out of range");
+  if (!(p->mu > 0.0) || !(p->mass > 0.0)) return fail(QC_ERR_INVALID, "qc_create: mu and mass must be > 0");
+  if (!(p->fzmin >= 0.0) || !(p->fzmax >= p->fzmin)) return fail(QC_ERR_INVALID, "qc_create: need 0 <= fzmin <= fzmax");
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j < i; j++)
+      if (std::fabs(p->S[6 * i + j] - p->S[6 * j + i]) > 1e-12 * (std::fabs(p->S[6 * i + i]) + std::fabs(p->S[6 * j + j])))
+        return fail(QC_ERR_INVALID, "qc_create: S must be symmetric");
+  bool diag = true;
+  for (int i = 0; i < 12; i++) {
+    if (!(p->W[12 * i + i] > 0.0)) return fail(QC_ERR_INVALID, "qc_create: W must be positive definite");
+    for (int j = 0; j < 12; j++)
+      if (i != j && p->W[12 * i + j] != 0.0) diag = false;
+  }
+  if (!diag) return fail(QC_ERR_INVALID, "qc_create: non-diagonal W not supported yet by this build");
+
+  qc_handle* h = new (std::nothrow) qc_handle();
+  if (!h) return fail(QC_ERR_INVALID, "qc_create: out of memory");
+  h->device = device;
+  h->diag_w = diag;
+  h->stage = nullptr;
+  h->stage_bytes = 0;
+  h->stream = nullptr;
+  qc::DevParams& d = h->dp;
+  std::memset(&d, 0, sizeof(d));
+  d.mu = p->mu; d.mass = p->mass; d.fzmin = p->fzmin; d.fzmax = p->fzmax;
+  std::memcpy(d.Ib, p->Ib, sizeof(d.Ib));
+  std::memcpy(d.S, p->S, sizeof(d.S));
+  if (!spd_inverse(p->S, 6, d.V)) { delete h; return fail(QC_ERR_INVALID, "qc_create: S must be positive definite"); }
+  for (int i = 0; i < 12; i++) d.w[i] = p->W[12 * i + i];
+  for (int i = 0; i < 4; i++) {
+    d.inv_wx[i] = 1.0 / d.w[3 * i];
+    d.inv_wy[i] = 1.0 / d.w[3 * i + 1];
+    for (int a = 0; a < 2; a++)
+      for (int b = 0; b < 2; b++)
+        d.inv_bz[4 * i + 2 * a + b] = 1.0 / (d.w[3 * i + 2] + p->mu * p->mu * (a * d.w[3 * i] + b * d.w[3 * i + 1]));
+  }
+  std::memcpy(d.kff, p->kff, sizeof(d.kff));
+  std::memcpy(d.kp_p, p->kp_p, sizeof(d.kp_p));
+  std::memcpy(d.kd_p, p->kd_p, sizeof(d.kd_p));
+  std::memcpy(d.kp_w, p->kp_w, sizeof(d.kp_w));
+  std::memcpy(d.kd_w, p->kd_w, sizeof(d.kd_w));
+  d.tol_d = 1e-9;
+  d.max_iter = p->max_iter > 0 ? p->max_iter : 200;
+  *out = h;
+  return QC_OK;
+}
+
+void qc_destroy(qc_handle* h) {
+  if (!h) return;
+  if (h->stage) {
+    (void)hipSetDevice(h->device);
+    (void)hipFree(h->stage);
+  }
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int qc_control_batch(qc_handle* h, size_t n, const qc_batch_in* in, const uint32_t* warm, const qc_batch_out* out, void* stream) {
+  if (!h || !in || !out) return fail(QC_ERR_INVALID, "qc_control_batch: null argument");
+  if (n == 0) return QC_OK;
+  if (!in->Rwb || !in->Rwb_d || !in->x || !in->xdot || !in->w || !in->x_d || !in->xdot_d || !in->w_d || !in->feet)
+    return fail(QC_ERR_INVALID, "qc_control_batch: null input array");
+  if (!out->grf_body || !out->status) return fail(QC_ERR_INVALID, "qc_control_batch: grf_body and status are required");
+  QC_HIP(hipSetDevice(h->device));
+  qc::BatchIn bi{in->Rwb, in->Rwb_d, in->x, in->xdot, in->w, in->x_d, in->xdot_d, in->w_d, in->feet, in->stance};
+  qc::BatchOut bo{out->grf_body, out->status, out->active_set, out->iterations};
+  const unsigned blocks = (unsigned)((n + 63) / 64);
+  hipLaunchKernelGGL(qc::balance_kernel<qc::EqpDiagW>, dim3(blocks), dim3(64), 0, (hipStream_t)stream, h->dp, (long)n, bi, warm, bo);
+  QC_HIP(hipGetLastError());
+  return QC_OK;
+}
+
+// host-pointer variant: one staging allocation, H2D, kernel, D2H, sync
+int qc_control_batch_host(qc_handle* h, size_t n, const qc_batch_in* in, const uint32_t* warm, const qc_batch_out* out) {
+  if (!h || !in || !out) return fail(QC_ERR_INVALID, "qc_control_batch_host: null argument");
+  if (n == 0) return QC_OK;
+  if (!in->Rwb || !in->Rwb_d || !in->x || !in->xdot || !in->w || !in->x_d || !in->xdot_d || !in->w_d || !in->feet)
+    return fail(QC_ERR_INVALID, "qc_control_batch_host: null input array");
+  if (!out->grf_body || !out->status) return fail(QC_ERR_INVALID, "qc_control_batch_host: grf_body and status are required");
+  QC_HIP(hipSetDevice(h->device));
+  if (!h->stream) QC_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  // layout (all 8-byte aligned): 48 doubles in, 12 doubles out, 4 x 4-byte words
+  const size_t per = 48 * 8 + 12 * 8 + 4 * 4 + 8;
+  const size_t need = n * per + 256;
+  if (need > h->stage_bytes) {
+    if (h->stage) QC_HIP(hipFree(h->stage));
+    h->stage = nullptr; h->stage_bytes = 0;
+    QC_HIP(hipMalloc(&h->stage, need));
+    h->stage_bytes = need;
+  }
+  char* base = (char*)h->stage;
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { char* p = base + off; off += (bytes + 15) & ~(size_t)15; return p; };
+  const size_t szs[9] = {9, 9, 3, 3, 3, 3, 3, 3, 12};
+  const double* src[9] = {in->Rwb, in->Rwb_d, in->x, in->xdot, in->w, in->x_d, in->xdot_d, in->w_d, in->feet};
+  double* dptr[9];
+  for (int k = 0; k < 9; k++) {
+    dptr[k] = (double*)carve(n * szs[k] * 8);
+    QC_HIP(hipMemcpyAsync(dptr[k], src[k], n * szs[k] * 8, hipMemcpyHostToDevice, h->stream));
+  }
+  uint8_t* d_st = nullptr;
+  if (in->stance) {
+    d_st = (uint8_t*)carve(n * 4);
+    QC_HIP(hipMemcpyAsync(d_st, in->stance, n * 4, hipMemcpyHostToDevice, h->stream));
+  }
+  uint32_t* d_warm = nullptr;
+  if (warm) {
+    d_warm = (uint32_t*)carve(n * 4);
+    QC_HIP(hipMemcpyAsync(d_warm, warm, n * 4, hipMemcpyHostToDevice, h->stream));
+  }
+  double* d_grf = (double*)carve(n * 12 * 8);
+  int32_t* d_status = (int32_t*)carve(n * 4);
+  uint32_t* d_act = out->active_set ? (uint32_t*)carve(n * 4) : nullptr;
+  int32_t* d_it = out->iterations ? (int32_t*)carve(n * 4) : nullptr;
+  if (off > h->stage_bytes) return fail(QC_ERR_INVALID, "qc_control_batch_host: staging overflow");
+  qc_batch_in din{dptr[0], dptr[1], dptr[2], dptr[3], dptr[4], dptr[5], dptr[6], dptr[7], dptr[8], d_st};
+  qc_batch_out dout{d_grf, d_status, d_act, d_it};
+  int rc = qc_control_batch(h, n, &din, d_warm, &dout, h->stream);
+  if (rc != QC_OK) return rc;
+  QC_HIP(hipMemcpyAsync(out->grf_body, d_grf, n * 12 * 8, hipMemcpyDeviceToHost, h->stream));
+  QC_HIP(hipMemcpyAsync(out->status, d_status, n * 4, hipMemcpyDeviceToHost, h->stream));
+  if (d_act) QC_HIP(hipMemcpyAsync(out->active_set, d_act, n * 4, hipMemcpyDeviceToHost, h->stream));
+  if (d_it) QC_HIP(hipMemcpyAsync(out->iterations, d_it, n * 4, hipMemcpyDeviceToHost, h->stream));
+  QC_HIP(hipStreamSynchronize(h->stream));
+  return QC_OK;
+}
+
+int qc_control(qc_handle* h, const double* Rwb, const double* Rwb_d, const double* x, const double* xdot,
+               const double* w, const double* x_d, const double* xdot_d, const double* w_d, const double* feet,
+               const uint8_t* stance, double* grf_body, int32_t* status) {
+  qc_batch_in in{Rwb, Rwb_d, x, xdot, w, x_d, xdot_d, w_d, feet, stance};
+  qc_batch_out out{grf_body, status, nullptr, nullptr};
+  return qc_control_batch_host(h, 1, &in, nullptr, &out);
+}
+
+}  // extern "C"

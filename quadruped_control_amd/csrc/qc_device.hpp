@@ -1,0 +1,368 @@
+// qc_device.hpp - device-side building blocks of the batched balance controller
+// (gfx950 / CDNA4, wave64, FP64 VALU; no MFMA on purpose: the per-robot
+// matrices are 6x6 / 12x12 and every lane owns a different robot).
+//
+// Execution model: ONE LANE = ONE ROBOT (one QP instance), 64 robots per
+// wavefront.  All per-robot state lives in VGPRs with compile-time indexing;
+// batch inputs are read straight from the per-argument arrays of qc_batch_in,
+// so consecutive lanes touch consecutive rows and every fetched cache line is
+// fully consumed by the wave.
+//
+// Reference being replaced: BalanceController::control(),
+// quadruped_controller/src/quadruped_controller/balance_controller.cpp:98-330
+// (cited below as BC.cpp).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define QC_DEV __device__ __forceinline__
+
+namespace qc {
+
+// Uniform (per-handle) constants; passed by value in the kernarg segment so
+// that they are fetched with scalar loads and used as SGPR operands.
+struct DevParams {
+  double mu, mass, fzmin, fzmax;
+  double Ib[9];
+  double S[36];        // wrench weight (general SPD)
+  double V[36];        // S^-1 (host-computed), used by the diagW formulation
+  double w[12];        // diag(W) (diagW formulation)
+  double inv_wx[4];    // 1 / w_x per foot
+  double inv_wy[4];    // 1 / w_y per foot
+  double inv_bz[16];   // [foot][|sx|*2+|sy|] 1 / (w_z + mu^2 (|sx| w_x + |sy| w_y))
+  double kff[6], kp_p[3], kd_p[3], kp_w[3], kd_w[3];
+  double tol_d;        // relative multiplier tolerance
+  int max_iter;
+  int pad;
+};
+
+struct BatchIn {
+  const double *Rwb, *Rwb_d, *x, *xdot, *w, *x_d, *xdot_d, *w_d, *feet;
+  const uint8_t* stance;
+};
+struct BatchOut {
+  double* grf_body;
+  int32_t* status;
+  uint32_t* active_set;
+  int32_t* iterations;
+};
+
+// ---------------------------------------------------------------- small math
+QC_DEV double rsqrt_nr(double d) {
+  // v_rsq_f64 seed + two Newton steps (full FP64 accuracy for d in normal range)
+  double y = __builtin_amdgcn_rsq(d);
+  double t = d * y;
+  double e = __builtin_fma(-t, y, 1.0);
+  y = __builtin_fma(y * 0.5, e, y);
+  t = d * y;
+  e = __builtin_fma(-t, y, 1.0);
+  y = __builtin_fma(y * 0.5, e, y);
+  return y;
+}
+
+// Rotation3d(mat).angleAxisTotal(): math/rigid3d.cpp:177-179,198-203
+// (Drake RotationMatrix::ToAngleAxis -> Eigen matrix->quaternion->angle-axis).
+QC_DEV void angle_axis_total(const double (&m)[9], double (&out)[3]) {
+  double qx, qy, qz, qw;
+  double t = m[0] + m[4] + m[8];
+  if (t > 0.0) {
+    t = sqrt(t + 1.0);
+    qw = 0.5 * t;
+    t = 0.5 / t;
+    qx = (m[7] - m[5]) * t;
+    qy = (m[2] - m[6]) * t;
+    qz = (m[3] - m[1]) * t;
+  } else if (m[0] >= m[4] && m[0] >= m[8]) {  // i = 0 (ties keep the lower index, as Eigen's > tests do)
+    t = sqrt(m[0] - m[4] - m[8] + 1.0);
+    qx = 0.5 * t;
+    t = 0.5 / t;
+    qw = (m[7] - m[5]) * t;
+    qy = (m[3] + m[1]) * t;
+    qz = (m[6] + m[2]) * t;
+  } else if (m[4] >= m[8]) {  // i = 1
+    t = sqrt(m[4] - m[8] - m[0] + 1.0);
+    qy = 0.5 * t;
+    t = 0.5 / t;
+    qw = (m[2] - m[6]) * t;
+    qz = (m[7] + m[5]) * t;
+    qx = (m[1] + m[3]) * t;
+  } else {  // i = 2
+    t = sqrt(m[8] - m[0] - m[4] + 1.0);
+    qz = 0.5 * t;
+    t = 0.5 / t;
+    qw = (m[3] - m[1]) * t;
+    qx = (m[2] + m[6]) * t;
+    qy = (m[5] + m[7]) * t;
+  }
+  double n = sqrt(qx * qx + qy * qy + qz * qz);
+  if (n != 0.0) {
+    double angle = 2.0 * atan2(n, fabs(qw));
+    double s = angle / (qw < 0.0 ? -n : n);
+    out[0] = qx * s;
+    out[1] = qy * s;
+    out[2] = qz * s;
+  } else {
+    out[0] = out[1] = out[2] = 0.0;
+  }
+}
+
+// Per-robot quantities every formulation needs: r_i = Rwb p_i (BC.cpp:244-248)
+// and the wrench target b (BC.cpp:126-139, 264-269).
+struct Wrench {
+  double r[4][3];
+  double b[6];
+};
+
+QC_DEV void load3(const double* __restrict__ p, long idx, double (&v)[3]) {
+  const double* q = p + 3 * idx;
+  v[0] = q[0]; v[1] = q[1]; v[2] = q[2];
+}
+QC_DEV void load9(const double* __restrict__ p, long idx, double (&v)[9]) {
+  const double* q = p + 9 * idx;
+#pragma unroll
+  for (int k = 0; k < 9; k++) v[k] = q[k];
+}
+
+// K0 + K2 + K3 of SURVEY.md 2.2: gather, PD wrench law, SRB dynamics rhs.
+QC_DEV void build_wrench(const DevParams& P, const BatchIn& in, long idx, double (&R)[9], Wrench& W) {
+  double Rd[9], x[3], xd[3], xdot[3], xdotd[3], w[3], wd[3];
+  load9(in.Rwb, idx, R);
+  load9(in.Rwb_d, idx, Rd);
+  load3(in.x, idx, x);
+  load3(in.x_d, idx, xd);
+  load3(in.xdot, idx, xdot);
+  load3(in.xdot_d, idx, xdotd);
+  load3(in.w, idx, w);
+  load3(in.w_d, idx, wd);
+  const double* fp = in.feet + 12 * idx;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    double p0 = fp[3 * i], p1 = fp[3 * i + 1], p2 = fp[3 * i + 2];
+#pragma unroll
+    for (int k = 0; k < 3; k++) W.r[i][k] = R[3 * k] * p0 + R[3 * k + 1] * p1 + R[3 * k + 2] * p2;  // BC.cpp:244-248
+  }
+  // linear PD, BC.cpp:126-129
+  double a[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) a[k] = P.kp_p[k] * (xd[k] - x[k]) + P.kd_p[k] * (xdotd[k] - xdot[k]);
+  a[0] += P.kff[0] * xdotd[0];
+  a[1] += P.kff[1] * xdotd[1];
+  a[2] += P.kff[2] * P.mass * 9.81;
+  // rotation error R_err = Rwb_d Rwb^T and angular PD, BC.cpp:133-139
+  double Re[9], e[3], al[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) Re[3 * i + j] = Rd[3 * i] * R[3 * j] + Rd[3 * i + 1] * R[3 * j + 1] + Rd[3 * i + 2] * R[3 * j + 2];
+  angle_axis_total(Re, e);
+#pragma unroll
+  for (int k = 0; k < 3; k++) al[k] = P.kp_w[k] * e[k] + P.kd_w[k] * (wd[k] - w[k]);
+  al[0] += P.kff[3] * wd[0];
+  al[1] += P.kff[4] * wd[1];
+  al[1] += P.kff[5] * wd[2];  // sic (index 1), BC.cpp:139
+  // b, BC.cpp:264-269; g_ = (0,0,-9.81) BC.cpp:76
+  W.b[0] = P.mass * a[0];
+  W.b[1] = P.mass * a[1];
+  W.b[2] = P.mass * (a[2] - 9.81);
+  // Iw = Rwb Ib Rwb^T (BC.cpp:251); Iw v = R (Ib (R^T v))
+  double t1[3], t2[3], u1[3], u2[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    t1[k] = R[k] * al[0] + R[3 + k] * al[1] + R[6 + k] * al[2];  // R^T al
+    t2[k] = R[k] * wd[0] + R[3 + k] * wd[1] + R[6 + k] * wd[2];  // R^T wd
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    u1[k] = P.Ib[3 * k] * t1[0] + P.Ib[3 * k + 1] * t1[1] + P.Ib[3 * k + 2] * t1[2];
+    u2[k] = P.Ib[3 * k] * t2[0] + P.Ib[3 * k + 1] * t2[1] + P.Ib[3 * k + 2] * t2[2];
+  }
+  double Ia[3], Iw[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    Ia[k] = R[3 * k] * u1[0] + R[3 * k + 1] * u1[1] + R[3 * k + 2] * u1[2];
+    Iw[k] = R[3 * k] * u2[0] + R[3 * k + 1] * u2[1] + R[3 * k + 2] * u2[2];
+  }
+  W.b[3] = Ia[0] + (wd[1] * Iw[2] - wd[2] * Iw[1]);
+  W.b[4] = Ia[1] + (wd[2] * Iw[0] - wd[0] * Iw[2]);
+  W.b[5] = Ia[2] + (wd[0] * Iw[1] - wd[1] * Iw[0]);
+}
+
+// ------------------------------------------------------------ active-set state
+// Each stance foot's feasible set { |fx|<=mu fz, |fy|<=mu fz, fzmin<=fz<=fzmax }
+// (BC.cpp:274-330: 5 two-sided rows per foot, of which 6 sides can bind) is
+// combinatorially a cube: axis X in {fx=-mu fz, free, fx=+mu fz}, same for Y,
+// axis Z in {fz=fzmin, free, fz=fzmax}.  State = (sx,sy,sz) in {-1,0,+1}^3.
+// Swing feet (BC.cpp:312-316: all five rows pinned to 0) are eliminated: f_i=0.
+struct Cube {
+  int sx[4], sy[4], sz[4];
+};
+
+QC_DEV uint32_t encode_states(const Cube& c) {
+  uint32_t wv = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    uint32_t f = (uint32_t)(c.sx[i] & 3) | ((uint32_t)(c.sy[i] & 3) << 2) | ((uint32_t)(c.sz[i] & 3) << 4);  // -1 -> 3
+    wv |= f << (6 * i);
+  }
+  return wv | 0x80000000u;  // bit 31: "valid warm word"
+}
+QC_DEV int dec2(uint32_t v) { return (v & 3u) == 3u ? -1 : ((v & 3u) == 1u ? 1 : 0); }
+QC_DEV void decode_states(uint32_t wv, Cube& c) {
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    uint32_t f = wv >> (6 * i);
+    c.sx[i] = dec2(f);
+    c.sy[i] = dec2(f >> 2);
+    c.sz[i] = dec2(f >> 4);
+  }
+}
+
+// Componentwise clamp of one foot into its frustum; reports the faces it hit.
+QC_DEV bool clamp_foot(double mu, double lo, double hi, double& fx, double& fy, double& fz, int& sx, int& sy, int& sz) {
+  bool ch = false;
+  sx = sy = sz = 0;
+  if (fz > hi) { fz = hi; sz = 1; ch = true; }
+  else if (fz < lo) { fz = lo; sz = -1; ch = true; }
+  double m = mu * fz;
+  if (fx > m) { fx = m; sx = 1; ch = true; }
+  else if (fx < -m) { fx = -m; sx = -1; ch = true; }
+  if (fy > m) { fy = m; sy = 1; ch = true; }
+  else if (fy < -m) { fy = -m; sy = -1; ch = true; }
+  return ch;
+}
+
+// Keeps the smallest ratio num/den (den > 0) without dividing.
+struct Ratio {
+  double num, den;
+  int code;  // foot*8 + axis*2 + (sign>0), -1 = none
+};
+QC_DEV void ratio_try(Ratio& best, double slack, double nd, int code) {
+  if (nd > 1e-14) {
+    double s = slack > 0.0 ? slack : 0.0;
+    if (s * best.den < best.num * nd) { best.num = s; best.den = nd; best.code = code; }
+  }
+}
+
+// -------------------------------------------------------------- EQP, diagonal W
+// Equality-constrained subproblem on the current face, 6-dimensional form.
+// With f = T y + p (T,p from the cube states), diagonal W and u = A f - b:
+//   (S^-1 + A~ B^-1 A~^T) v = -(b - A p),   v = S u,   y = -B^-1 A~^T v
+// where A~ = A T (6 x 12) and B = T^T W T is DIAGONAL for diagonal W.  One
+// 6x6 Cholesky per working-set recalculation; the Hessian Q = 2(A^T S A + W)
+// of BC.cpp:152 is never formed.  The gradient needed for the multipliers is
+// g = Q f + c = 2 (A^T v + W f).
+QC_DEV bool eqp_diagw(const DevParams& P, const Wrench& Wr, const Cube& C, uint32_t stance_mask, double (&f)[12], double (&g)[12]) {
+  double M[21];
+  // packed lower triangle index r*(r+1)/2 + c
+#define MI(r, c) ((r) * ((r) + 1) / 2 + (c))
+#pragma unroll
+  for (int r = 0; r < 6; r++)
+#pragma unroll
+    for (int c = 0; c <= r; c++) M[MI(r, c)] = P.V[6 * r + c];
+  double rhs[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) rhs[k] = -Wr.b[k];
+
+  double q[4][6], ix[4], iy[4], iz[4], fzfix[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const bool st = (stance_mask >> i) & 1u;
+    const double rx = Wr.r[i][0], ry = Wr.r[i][1], rz = Wr.r[i][2];
+    const int sx = C.sx[i], sy = C.sy[i], sz = C.sz[i];
+    const double mx = P.mu * (double)sx, my = P.mu * (double)sy;
+    fzfix[i] = st ? (sz > 0 ? P.fzmax : (sz < 0 ? P.fzmin : 0.0)) : 0.0;
+    ix[i] = (st && sx == 0) ? P.inv_wx[i] : 0.0;
+    iy[i] = (st && sy == 0) ? P.inv_wy[i] : 0.0;
+    const int sel = (sx != 0 ? 2 : 0) + (sy != 0 ? 1 : 0);
+    const double ibz = sel == 0 ? P.inv_bz[4 * i] : (sel == 1 ? P.inv_bz[4 * i + 1] : (sel == 2 ? P.inv_bz[4 * i + 2] : P.inv_bz[4 * i + 3]));
+    iz[i] = (st && sz == 0) ? ibz : 0.0;
+    q[i][0] = mx; q[i][1] = my; q[i][2] = 1.0;
+    q[i][3] = ry - rz * my;
+    q[i][4] = rz * mx - rx;
+    q[i][5] = rx * my - ry * mx;
+#pragma unroll
+    for (int k = 0; k < 6; k++) rhs[k] = __builtin_fma(fzfix[i], q[i][k], rhs[k]);
+    // x slot column (1,0,0, 0, rz, -ry)
+    {
+      const double t4 = ix[i] * rz, t5 = -ix[i] * ry;
+      M[MI(0, 0)] += ix[i];
+      M[MI(4, 0)] += t4;
+      M[MI(5, 0)] += t5;
+      M[MI(4, 4)] = __builtin_fma(t4, rz, M[MI(4, 4)]);
+      M[MI(5, 4)] = __builtin_fma(t5, rz, M[MI(5, 4)]);
+      M[MI(5, 5)] = __builtin_fma(t5, -ry, M[MI(5, 5)]);
+    }
+    // y slot column (0,1,0, -rz, 0, rx)
+    {
+      const double t3 = -iy[i] * rz, t5 = iy[i] * rx;
+      M[MI(1, 1)] += iy[i];
+      M[MI(3, 1)] += t3;
+      M[MI(5, 1)] += t5;
+      M[MI(3, 3)] = __builtin_fma(t3, -rz, M[MI(3, 3)]);
+      M[MI(5, 3)] = __builtin_fma(t5, -rz, M[MI(5, 3)]);
+      M[MI(5, 5)] = __builtin_fma(t5, rx, M[MI(5, 5)]);
+    }
+    // z slot column q
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+      const double tq = iz[i] * q[i][c];
+#pragma unroll
+      for (int r = c; r < 6; r++) M[MI(r, c)] = __builtin_fma(q[i][r], tq, M[MI(r, c)]);
+    }
+  }
+  // Cholesky M = L L^T (in place; diagonal holds 1/L_kk)
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    double d = M[MI(k, k)];
+#pragma unroll
+    for (int m = 0; m < k; m++) d = __builtin_fma(-M[MI(k, m)], M[MI(k, m)], d);
+    ok = ok && (d > 0.0);
+    const double rinv = rsqrt_nr(d);
+    M[MI(k, k)] = rinv;
+#pragma unroll
+    for (int r = k + 1; r < 6; r++) {
+      double t = M[MI(r, k)];
+#pragma unroll
+      for (int m = 0; m < k; m++) t = __builtin_fma(-M[MI(r, m)], M[MI(k, m)], t);
+      M[MI(r, k)] = t * rinv;
+    }
+  }
+  // solve L L^T v = rhs
+  double v[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    double t = rhs[k];
+#pragma unroll
+    for (int m = 0; m < k; m++) t = __builtin_fma(-M[MI(k, m)], v[m], t);
+    v[k] = t * M[MI(k, k)];
+  }
+#pragma unroll
+  for (int k = 5; k >= 0; k--) {
+    double t = v[k];
+#pragma unroll
+    for (int m = k + 1; m < 6; m++) t = __builtin_fma(-M[MI(m, k)], v[m], t);
+    v[k] = t * M[MI(k, k)];
+  }
+#undef MI
+  // back to forces and gradient
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const double rx = Wr.r[i][0], ry = Wr.r[i][1], rz = Wr.r[i][2];
+    const double yx = -ix[i] * (v[0] + rz * v[4] - ry * v[5]);
+    const double yy = -iy[i] * (v[1] - rz * v[3] + rx * v[5]);
+    double qv = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) qv = __builtin_fma(q[i][k], v[k], qv);
+    const double fz = fzfix[i] - iz[i] * qv;
+    const double fx = __builtin_fma(q[i][0], fz, yx);
+    const double fy = __builtin_fma(q[i][1], fz, yy);
+    f[3 * i] = fx; f[3 * i + 1] = fy; f[3 * i + 2] = fz;
+    g[3 * i] = 2.0 * (v[0] + v[4] * rz - v[5] * ry + P.w[3 * i] * fx);
+    g[3 * i + 1] = 2.0 * (v[1] + v[5] * rx - v[3] * rz + P.w[3 * i + 1] * fy);
+    g[3 * i + 2] = 2.0 * (v[2] + v[3] * ry - v[4] * rx + P.w[3 * i + 2] * fz);
+  }
+  return ok;
+}
+
+}  // namespace qc

@@ -1,0 +1,94 @@
+"""-m gpu: HIP path (through the C ABI) vs the oracle and the golden fixtures."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "balance_golden.json")
+FIELDS = ("Rwb", "Rwb_d", "x", "xdot", "w", "x_d", "xdot_d", "w_d", "feet")
+RTOL = 1e-6  # north_star bar is 1e-4 relative; we hold the kernel to 1e-6 of max|GRF|
+
+
+def _relerr(a, b):
+    scale = np.maximum(1.0, np.abs(b).max(axis=-1, keepdims=True))
+    return float(np.max(np.abs(a - b) / scale))
+
+
+@pytest.fixture(scope="module")
+def q(built):
+    import torch
+
+    assert torch.cuda.is_available()
+    import quadruped_control_amd as q
+
+    return q
+
+
+def _gold_batches():
+    with open(GOLD) as f:
+        gold = json.load(f)
+    groups = {}
+    for c in gold["cases"]:
+        groups.setdefault((c["mu"], c["fzmin"], c["fzmax"]), []).append(c)
+    return groups
+
+
+def test_golden_fixtures(q):
+    for (mu, fzmin, fzmax), cases in _gold_batches().items():
+        P = q.cheetah_params(mu)
+        P["fzmin"], P["fzmax"] = fzmin, fzmax
+        ctl = q.BalanceController.from_params(P)
+        batch = {k: np.array([c[k] for c in cases], dtype=np.float64) for k in FIELDS}
+        batch["stance"] = np.array([c["stance"] for c in cases], dtype=np.uint8)
+        out = ctl.control_batch_host(batch, want_iterations=True)
+        assert (out["status"] == 0).all()
+        exp = np.array([c["grf_body"] for c in cases])
+        assert _relerr(out["grf_body"], exp) < RTOL
+        # swing legs exactly zero
+        sw = np.repeat(batch["stance"] == 0, 3, axis=1)
+        assert np.all(out["grf_body"][sw] == 0.0)
+
+
+@pytest.mark.parametrize("cfg,n", [(2, 4096), (3, 8192)])
+def test_against_c_oracle(q, cfg, n):
+    import torch
+
+    from oracle import c_oracle
+    from quadruped_control_amd import workloads
+
+    P = q.cheetah_params(0.6)
+    batch = workloads.config2(n) if cfg == 2 else workloads.config3(n)
+    ctl = q.BalanceController.from_params(P)
+    out = ctl.control_batch(q.to_device(batch), want_iterations=True, want_active_set=True)
+    torch.cuda.synchronize()
+    grf = out["grf_body"].cpu().numpy()
+    assert (out["status"].cpu().numpy() == 0).all()
+    ref, st, _ = c_oracle.control_batch(P, batch, threads=8)
+    assert (st == 0).all()
+    assert _relerr(grf, ref) < RTOL
+    it = out["iterations"].cpu().numpy()
+    assert it.max() <= 200 and it.min() >= 1
+
+
+def test_single_robot_control_kat1(q):
+    """config 1 / KAT1 through the reference-shaped control()."""
+    P = q.cheetah_params(0.8)
+    ctl = q.BalanceController.from_params(P)
+    feet = {"RL": [-0.196, 0.127, -0.26], "FL": [0.196, 0.127, -0.26], "RR": [-0.196, -0.127, -0.26], "FR": [0.196, -0.127, -0.26]}
+    I = np.eye(3)
+    z = np.zeros(3)
+    x = np.array([0, 0, 0.26])
+    fm = ctl.control(I, I, x, z, z, x, z, z, feet)
+    assert sorted(fm) == ["FL", "FR", "RL", "RR"]
+    for v in fm.values():
+        assert abs(v[2] + 17.5353311617) < 1e-8 and abs(v[0]) < 1e-7 and abs(v[1]) < 1e-7
+    # trot: swing legs are omitted from the map (balance_controller.cpp:222)
+    gait = {"RL": (q.LegState.stance, 0.0), "FL": (q.LegState.swing, 0.6), "RR": (q.LegState.swing, 0.6), "FR": (q.LegState.stance, 0.0)}
+    fm = ctl.control(I, I, x, z, z, x, z, z, feet, gait)
+    assert sorted(fm) == ["FR", "RL"]
+    assert abs(fm["RL"][2] + 35.0705746471) < 1e-8
+    with pytest.raises(KeyError):
+        ctl.control(I, I, x, z, z, x, z, z, {"RL": [0, 0, 0]})
