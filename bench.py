@@ -106,10 +106,14 @@ def cpu_baseline(P, batch, budget_s=4.0):
     of wall time (~10-30 s of CPU work on >= 4 threads)."""
     from oracle import c_oracle
 
+    import numpy as np
+
     n_all = batch["x"].shape[0]
-    n = min(n_all, 4096)
-    sample = {k: v[:n] for k, v in batch.items()}
     threads = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    base = min(n_all, 4096)
+    tile = max(1, (256 * threads + base - 1) // base)  # >= 256 robots per thread per call
+    sample = {k: np.ascontiguousarray(np.tile(v[:base], (tile, 1))) for k, v in batch.items()}
+    n = base * tile
     c_oracle.control_batch(P, {k: v[:64] for k, v in sample.items()}, threads=threads)  # warm-up / thread pool
     t0 = time.perf_counter()
     c_oracle.control_batch(P, {k: v[:512] for k, v in sample.items()}, threads=1)
@@ -122,9 +126,27 @@ def cpu_baseline(P, batch, budget_s=4.0):
             break
     dt = time.perf_counter() - t0
     return {"value": reps * n / dt, "unit": "QPs/s", "cores": threads, "kind": "port",
-            "sample": f"first {n} robots of the benchmark batch x {reps} repetitions, {threads} OpenMP threads, "
+            "sample": f"first {base} robots of the benchmark batch tiled x{tile} = {n} robots per call x {reps} calls, {threads} OpenMP threads, "
                       f"{dt:.1f} s wall; C restatement (textbook primal active set), not qpOASES",
             "single_thread_value": one}
+
+
+def pmc_traffic(cfg, n):
+    """HBM bytes per launch from the newest committed PMC pass of this workload
+    (profiles/rNN_cfg<cfg>.json, produced by tools/profile_r.sh +
+    tools/summarize_profile.py: separate --pmc FETCH_SIZE / WRITE_SIZE passes,
+    FETCH_SIZE doubled per MI355X_MICROARCH.md).  None if no matching pass."""
+    import glob
+
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_cfg{cfg}.json"))):
+        try:
+            d = json.load(open(f))
+            if d.get("bench_line", {}).get("config", {}).get("robots_per_gpu") == n and "traffic" in d:
+                best = (d["traffic"]["hbm_bytes_per_launch"], os.path.relpath(f, ROOT))
+        except Exception:
+            pass
+    return best
 
 
 def main():
@@ -163,16 +185,12 @@ def main():
     n = args.n or CONFIG_N[cfg]
     res = run_config(ctl, q, cfg, n, rank * n, args.steps, args.warmup, dist, device)
 
-    wall, solved_total = res["wall"], res["solved"]
-    if dist is not None:
-        t = torch.tensor([wall], dtype=torch.float64, device=f"cuda:{device}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)  # max over ranks
-        s = torch.tensor([res["solved"]], dtype=torch.int64, device=f"cuda:{device}")
-        dist.all_reduce(s, op=dist.ReduceOp.SUM)
-        wall, solved_total = float(t.item()), int(s.item())
+    from quadruped_control_amd.sharding import reduce_counters
+
+    wall, solved_total, total_robots = reduce_counters(dist, res["wall"], res["solved"], n,
+                                                       device=f"cuda:{device}" if dist is not None else None)
 
     if rank == 0:
-        total_robots = n * world
         bytes_per = BYTES_PER_ROBOT_WARM if res["warm"] else BYTES_PER_ROBOT_COLD
         kernel_s = res["event_s"] / args.steps
         achieved = bytes_per * n / kernel_s / 1e9
@@ -198,6 +216,10 @@ def main():
                          "avg_kernel_us": kernel_s * 1e6,
                          "note": "latency/FP64-VALU bound active-set solve; traffic from the PMC pass is in profiles/"},
         }
+        tr = pmc_traffic(cfg, n)
+        if tr is not None:
+            line["roofline"]["traffic"] = tr[0]
+            line["roofline"]["traffic_source"] = tr[1] + " (rocprofv3 --pmc pass of this command, not re-measured in this run)"
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(P, res["batch"])
         if world == 1 and not args.no_sweep:

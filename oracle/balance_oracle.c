@@ -228,7 +228,11 @@ int oracle_qp_solve(const double* H, const double* g, const double* C, const dou
   /* Feasible start: the reference's bounds always admit f_i = (0,0,lb of the
    * fz row) per foot (BC.cpp:300-301: lbf[4]=fzmin; swing rows are all 0). */
   for (int k = 0; k < NV; k++) f[k] = 0.0;
-  for (int i = 0; i < 4; i++) f[3 * i + 2] = lb[5 * i + 4];
+  /* fz = fzmin when that is a regular point of the foot's feasible set;
+   * with fzmin = 0 it would be the cone apex (five rows active on three
+   * variables, a degenerate vertex where the textbook method can cycle), so
+   * start from the middle of the fz range instead. */
+  for (int i = 0; i < 4; i++) f[3 * i + 2] = (lb[5 * i + 4] > 0.0 || lb[5 * i + 4] == ub[5 * i + 4]) ? lb[5 * i + 4] : 0.5 * (lb[5 * i + 4] + ub[5 * i + 4]);
   int ws[NC];      /* 0 free, +1 at ub, -1 at lb, 2 equality, 3 redundant equality */
   int idx[NC], m = 0;
   const double ftol = 1e-9;
@@ -256,7 +260,10 @@ int oracle_qp_solve(const double* H, const double* g, const double* C, const dou
 
   double lam[NC];
   int it;
+  int stalled = 0; /* consecutive working-set changes without movement; > 12 switches to Bland's
+                      least-index rule, which cannot cycle at a degenerate vertex (cone apex) */
   for (it = 0; it < max_iter; it++) {
+    const int bland = stalled > 12;
     /* KKT system of the equality-constrained subproblem */
     double M[KMAX * KMAX], rhs[KMAX];
     int n = NV + m;
@@ -273,26 +280,36 @@ int oracle_qp_solve(const double* H, const double* g, const double* C, const dou
     if (lin_solve(M, rhs, n)) return ORACLE_NOT_PD;
     double d[NV];
     for (int k = 0; k < NV; k++) d[k] = rhs[k] - f[k];
-    /* ratio test over rows outside the working set */
-    double alpha = 1.0;
-    int block = -1, bside = 0;
-    for (int r = 0; r < NC; r++) {
-      if (ws[r]) continue;
-      double cd = 0.0, cf = 0.0;
-      for (int k = 0; k < NV; k++) { cd += C[r * NV + k] * d[k]; cf += C[r * NV + k] * f[k]; }
-      if (cd > 1e-13) {
-        double a = (ub[r] - cf) / cd;
-        if (a < 0) a = 0;
-        if (a < alpha) { alpha = a; block = r; bside = 1; }
-      } else if (cd < -1e-13) {
-        double a = (lb[r] - cf) / cd;
-        if (a < 0) a = 0;
-        if (a < alpha) { alpha = a; block = r; bside = -1; }
+    /* ratio test over rows outside the working set.  A row that is linearly
+     * dependent on the working set cannot really block (its c.d is rounding
+     * noise, e.g. the fz>=0 row once three cone rows pin a foot to the apex):
+     * it is skipped and the test repeated. */
+    int skip[NC] = {0};
+    double alpha;
+    int block, bside;
+    for (;;) {
+      alpha = 1.0; block = -1; bside = 0;
+      for (int r = 0; r < NC; r++) {
+        if (ws[r] || skip[r]) continue;
+        double cd = 0.0, cf = 0.0;
+        for (int k = 0; k < NV; k++) { cd += C[r * NV + k] * d[k]; cf += C[r * NV + k] * f[k]; }
+        if (cd > 1e-13) {
+          double a = (ub[r] - cf) / cd;
+          if (a < 0) a = 0;
+          if (a < alpha && !(bland && block >= 0 && alpha <= 1e-12)) { alpha = a; block = r; bside = 1; }
+        } else if (cd < -1e-13) {
+          double a = (lb[r] - cf) / cd;
+          if (a < 0) a = 0;
+          if (a < alpha && !(bland && block >= 0 && alpha <= 1e-12)) { alpha = a; block = r; bside = -1; }
+        }
       }
+      if (block < 0 || (m < NV && independent(C, idx, m, C + block * NV))) break;
+      skip[block] = 1;
     }
     if (block >= 0) {
+      if (alpha <= 1e-12) stalled++; else stalled = 0;
       for (int k = 0; k < NV; k++) f[k] += alpha * d[k];
-      if (m < NV && independent(C, idx, m, C + block * NV)) { ws[block] = bside; idx[m++] = block; }
+      ws[block] = bside; idx[m++] = block;
       continue;
     }
     for (int k = 0; k < NV; k++) f[k] = rhs[k];
@@ -305,7 +322,7 @@ int oracle_qp_solve(const double* H, const double* g, const double* C, const dou
       int r = idx[t];
       lam[r] = rhs[NV + t];
       double viol = (ws[r] == 1) ? -lam[r] : (ws[r] == -1 ? lam[r] : 0.0);
-      if (viol > 1e-10 * gs && viol > wv) { wv = viol; worst = t; }
+      if (viol > 1e-10 * gs && (bland ? (worst < 0 || idx[t] < idx[worst]) : viol > wv)) { wv = viol; worst = t; }
     }
     if (worst < 0) {
       if (lam_out) memcpy(lam_out, lam, sizeof(lam));

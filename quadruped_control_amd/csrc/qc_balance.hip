@@ -27,100 +27,119 @@ namespace qc {
 //           multiplier; stop when all multipliers are >= 0 (KKT).
 // The QP is strictly convex (W > 0), so the KKT point is THE minimiser qpOASES
 // returns in the reference (BC.cpp:177-210).
-// Per-lane solver state and one working-set recalculation.
+// Per-lane solver state.  All lanes of a wave execute the same working-set
+// recalculation in lockstep; everything below is straight-line, select-based
+// code (no per-lane branches) so the only divergence cost is the iteration
+// count of the slowest lane.
 template <class Eqp>
 struct LaneState {
   const DevParams& P;
   const Wrench& Wr;
-  const uint32_t stance_mask;
   Eqp& eqp;
   Cube& C;
+  double lo[4], hi[4];  // per-foot fz bounds; (0,0) pins a swing foot to f = 0
   double f[12];
   int status = QC_MAX_ITER;
   int iters = 0;
-  bool have_f = false, done = false;
+  bool done = false;
 
-  QC_DEV void step() {
+  // first working-set recalculation: f = clamp(EQP(S0))
+  QC_DEV void first() {
     double fh[12], g[12];
-    iters++;
-    if (!eqp.solve(P, Wr, C, stance_mask, fh, g)) { status = QC_NOT_PD; done = true; return; }
-
-    if (!have_f) {
-      // first point: clamp f^ into the frusta
-      have_f = true;
-      bool changed = false;
-      Cube Cc;
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        f[3 * i] = fh[3 * i]; f[3 * i + 1] = fh[3 * i + 1]; f[3 * i + 2] = fh[3 * i + 2];
-        Cc.sx[i] = Cc.sy[i] = Cc.sz[i] = 0;
-        if ((stance_mask >> i) & 1u)
-          changed |= clamp_foot(P.mu, P.fzmin, P.fzmax, f[3 * i], f[3 * i + 1], f[3 * i + 2], Cc.sx[i], Cc.sy[i], Cc.sz[i]);
-      }
-      if (changed) { C = Cc; return; }
-    } else {
-      Ratio best;
-      best.num = 1.0; best.den = 1.0; best.code = -1;
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        if (!((stance_mask >> i) & 1u)) continue;
-        const double fx = f[3 * i], fy = f[3 * i + 1], fz = f[3 * i + 2];
-        const double dx = fh[3 * i] - fx, dy = fh[3 * i + 1] - fy, dz = fh[3 * i + 2] - fz;
-        if (C.sz[i] == 0) {
-          ratio_try(best, P.fzmax - fz, dz, i * 8 + 4 + 1);
-          ratio_try(best, fz - P.fzmin, -dz, i * 8 + 4 + 0);
-        }
-        const double m = P.mu * fz, md = P.mu * dz;
-        if (C.sx[i] == 0) {
-          ratio_try(best, m - fx, dx - md, i * 8 + 0 + 1);
-          ratio_try(best, m + fx, -dx - md, i * 8 + 0 + 0);
-        }
-        if (C.sy[i] == 0) {
-          ratio_try(best, m - fy, dy - md, i * 8 + 2 + 1);
-          ratio_try(best, m + fy, -dy - md, i * 8 + 2 + 0);
-        }
-      }
-      if (best.code >= 0) {
-        const double alpha = best.num / best.den;
-#pragma unroll
-        for (int k = 0; k < 12; k++) f[k] = __builtin_fma(alpha, fh[k] - f[k], f[k]);
-        const int foot = best.code >> 3, axis = (best.code >> 1) & 3, sg = (best.code & 1) ? 1 : -1;
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-          if (i == foot) {
-            if (axis == 0) C.sx[i] = sg;
-            else if (axis == 1) C.sy[i] = sg;
-            else C.sz[i] = sg;
-          }
-        return;
-      }
-    }
-
-    // full step: f = f^; test the multipliers of the active faces
-    double gs = 1.0;
-#pragma unroll
-    for (int k = 0; k < 12; k++) { f[k] = fh[k]; gs = fmax(gs, fabs(g[k])); }
-    double worst = -P.tol_d * gs;
-    int wcode = -1;
+    iters = 1;
+    const bool ok = eqp.solve(P, Wr, C, lo, hi, fh, g);
+    bool changed = false;
+    Cube Cc;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      if (!((stance_mask >> i) & 1u)) continue;
+      f[3 * i] = fh[3 * i]; f[3 * i + 1] = fh[3 * i + 1]; f[3 * i + 2] = fh[3 * i + 2];
+      changed |= clamp_foot(P.mu, lo[i], hi[i], f[3 * i], f[3 * i + 1], f[3 * i + 2], Cc.sx[i], Cc.sy[i], Cc.sz[i]);
+    }
+    // f^ feasible: it is the minimiser on the start face -> multiplier test
+    int wcode;
+    const bool opt = multipliers_ok(g, wcode);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      C.sx[i] = changed ? Cc.sx[i] : ((wcode == 3 * i + 0) ? 0 : C.sx[i]);
+      C.sy[i] = changed ? Cc.sy[i] : ((wcode == 3 * i + 1) ? 0 : C.sy[i]);
+      C.sz[i] = changed ? Cc.sz[i] : ((wcode == 3 * i + 2) ? 0 : C.sz[i]);
+    }
+    if (!ok) { status = QC_NOT_PD; done = true; }
+    else if (!changed && opt) { status = QC_SOLVED; done = true; }
+  }
+
+  // multiplier test on the current face: true if all active faces have
+  // lambda >= -tol; otherwise wcode = 3*foot+axis of the most negative one.
+  QC_DEV bool multipliers_ok(const double (&g)[12], int& wcode) const {
+    double gs = 1.0;
+#pragma unroll
+    for (int k = 0; k < 12; k++) gs = fmax(gs, fabs(g[k]));
+    double cand[12];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
       const double lx = -(double)C.sx[i] * g[3 * i];
       const double ly = -(double)C.sy[i] * g[3 * i + 1];
       const double lz = (double)C.sz[i] * (P.mu * (lx + ly) - g[3 * i + 2]);
-      if (C.sz[i] != 0 && lz < worst) { worst = lz; wcode = i * 4 + 2; }
-      if (C.sx[i] != 0 && lx < worst) { worst = lx; wcode = i * 4 + 0; }
-      if (C.sy[i] != 0 && ly < worst) { worst = ly; wcode = i * 4 + 1; }
+      cand[3 * i + 0] = tag(C.sx[i] != 0 ? lx : QC_BIG, 3 * i + 0);
+      cand[3 * i + 1] = tag(C.sy[i] != 0 ? ly : QC_BIG, 3 * i + 1);
+      cand[3 * i + 2] = tag(C.sz[i] != 0 ? lz : QC_BIG, 3 * i + 2);
     }
-    if (wcode < 0) { status = QC_SOLVED; done = true; return; }
 #pragma unroll
-    for (int i = 0; i < 4; i++)
-      if (i == (wcode >> 2)) {
-        const int axis = wcode & 3;
-        if (axis == 0) C.sx[i] = 0;
-        else if (axis == 1) C.sy[i] = 0;
-        else C.sz[i] = 0;
-      }
+    for (int k = 0; k < 6; k++) cand[k] = fmin(cand[k], cand[k + 6]);
+#pragma unroll
+    for (int k = 0; k < 3; k++) cand[k] = fmin(cand[k], cand[k + 3]);
+    const double worst = fmin(fmin(cand[0], cand[1]), cand[2]);
+    const bool ok = !(worst < -P.tol_d * gs);
+    wcode = ok ? -1 : tag_code(worst);
+    return ok;
+  }
+
+  // one working-set recalculation from a feasible f
+  QC_DEV void step() {
+    double fh[12], g[12];
+    iters++;
+    const bool ok = eqp.solve(P, Wr, C, lo, hi, fh, g);
+    // ratio test over the faces outside the working set (tree min, code in the low bits)
+    double cand[24];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const double fx = f[3 * i], fy = f[3 * i + 1], fz = f[3 * i + 2];
+      const double dx = fh[3 * i] - fx, dy = fh[3 * i + 1] - fy, dz = fh[3 * i + 2] - fz;
+      const double m = P.mu * fz, md = P.mu * dz;
+      const bool zf = C.sz[i] == 0, xf = C.sx[i] == 0, yf = C.sy[i] == 0;
+      cand[6 * i + 0] = step_cand(m + fx, xf ? -dx - md : 0.0, 6 * i + 0);  // X-
+      cand[6 * i + 1] = step_cand(m - fx, xf ? dx - md : 0.0, 6 * i + 1);   // X+
+      cand[6 * i + 2] = step_cand(m + fy, yf ? -dy - md : 0.0, 6 * i + 2);  // Y-
+      cand[6 * i + 3] = step_cand(m - fy, yf ? dy - md : 0.0, 6 * i + 3);   // Y+
+      cand[6 * i + 4] = step_cand(fz - lo[i], zf ? -dz : 0.0, 6 * i + 4);   // Z-
+      cand[6 * i + 5] = step_cand(hi[i] - fz, zf ? dz : 0.0, 6 * i + 5);    // Z+
+    }
+#pragma unroll
+    for (int k = 0; k < 12; k++) cand[k] = fmin(cand[k], cand[k + 12]);
+#pragma unroll
+    for (int k = 0; k < 6; k++) cand[k] = fmin(cand[k], cand[k + 6]);
+#pragma unroll
+    for (int k = 0; k < 3; k++) cand[k] = fmin(cand[k], cand[k + 3]);
+    const double amin = fmin(fmin(cand[0], cand[1]), cand[2]);
+    const bool blocked = amin < 1.0e299;
+    const int bcode = blocked ? tag_code(amin) : -1;
+    const double alpha = fmin(amin, 1.0);
+#pragma unroll
+    for (int k = 0; k < 12; k++) f[k] = blocked ? __builtin_fma(alpha, fh[k] - f[k], f[k]) : fh[k];
+    // multiplier test (meaningful after a full step only)
+    int wcode;
+    const bool opt = multipliers_ok(g, wcode);
+    if (blocked) wcode = -1;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      int sx = C.sx[i], sy = C.sy[i], sz = C.sz[i];
+      sx = (bcode == 6 * i + 0) ? -1 : ((bcode == 6 * i + 1) ? 1 : ((wcode == 3 * i + 0) ? 0 : sx));
+      sy = (bcode == 6 * i + 2) ? -1 : ((bcode == 6 * i + 3) ? 1 : ((wcode == 3 * i + 1) ? 0 : sy));
+      sz = (bcode == 6 * i + 4) ? -1 : ((bcode == 6 * i + 5) ? 1 : ((wcode == 3 * i + 2) ? 0 : sz));
+      C.sx[i] = sx; C.sy[i] = sy; C.sz[i] = sz;
+    }
+    if (!ok) { status = QC_NOT_PD; done = true; }
+    else if (!blocked && opt) { status = QC_SOLVED; done = true; }
   }
 };
 
@@ -154,9 +173,25 @@ __global__ __launch_bounds__(64) void balance_kernel(const DevParams P, const lo
       if (!((stance_mask >> i) & 1u)) C.sx[i] = C.sy[i] = C.sz[i] = 0;
   }
 
-  LaneState<Eqp> L{P, Wr, stance_mask, eqp, C};
+  LaneState<Eqp> L{P, Wr, eqp, C};
 #pragma unroll
-  for (int k = 0; k < 12; k++) L.f[k] = 0.0;
+  for (int i = 0; i < 4; i++) {
+    const bool st = (stance_mask >> i) & 1u;
+    L.lo[i] = st ? P.fzmin : 0.0;
+    L.hi[i] = st ? P.fzmax : 0.0;
+  }
+  // non-finite inputs poison b or r: report them as QC_NOT_PD instead of iterating on NaNs
+  double fin = 0.0;
+#pragma unroll
+  for (int k = 0; k < 6; k++) fin = __builtin_fma(Wr.b[k], 0.0, fin);
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int k = 0; k < 3; k++) fin = __builtin_fma(Wr.r[i][k], 0.0, fin);
+#pragma unroll
+  for (int k = 0; k < 9; k++) fin = __builtin_fma(R[k], 0.0, fin);
+  L.first();
+  if (!(fin == 0.0)) { L.status = QC_NOT_PD; L.done = true; }
   for (;;) {
     if (!L.done && L.iters >= P.max_iter) L.done = true;  // status stays QC_MAX_ITER
     if (__builtin_amdgcn_ballot_w64(!L.done) == 0) break;  // wave-uniform exit
@@ -184,8 +219,8 @@ __global__ __launch_bounds__(64) void balance_kernel(const DevParams P, const lo
 
 struct EqpDiagW {
   QC_DEV EqpDiagW(const DevParams&, const Wrench&) {}
-  QC_DEV bool solve(const DevParams& P, const Wrench& Wr, const Cube& C, uint32_t stance_mask, double (&f)[12], double (&g)[12]) {
-    return eqp_diagw(P, Wr, C, stance_mask, f, g);
+  QC_DEV bool solve(const DevParams& P, const Wrench& Wr, const Cube& C, const double (&lo)[4], const double (&hi)[4], double (&f)[12], double (&g)[12]) {
+    return eqp_diagw(P, Wr, C, lo, hi, f, g);
   }
 };
 
@@ -297,7 +332,8 @@ int qc_create(const qc_params* p, int device, qc_handle** out) {
   std::memcpy(d.kd_p, p->kd_p, sizeof(d.kd_p));
   std::memcpy(d.kp_w, p->kp_w, sizeof(d.kp_w));
   std::memcpy(d.kd_w, p->kd_w, sizeof(d.kd_w));
-  d.tol_d = 1e-9;
+  d.tol_d = 1e-12;  // relative to 1+|grad|_inf: W ~ 1e-5 makes the primal very sensitive to a wrongly kept weakly-active face
+  if (const char* e = std::getenv("QC_TOL_D")) d.tol_d = std::atof(e);  // development knob
   d.max_iter = p->max_iter > 0 ? p->max_iter : 200;
   *out = h;
   return QC_OK;

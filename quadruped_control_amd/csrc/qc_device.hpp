@@ -217,30 +217,40 @@ QC_DEV void decode_states(uint32_t wv, Cube& c) {
   }
 }
 
-// Componentwise clamp of one foot into its frustum; reports the faces it hit.
+// Componentwise clamp of one foot into its frustum (branch-free); returns the
+// faces it hit.  lo/hi are the foot's own fz bounds (0,0 for a swing foot).
 QC_DEV bool clamp_foot(double mu, double lo, double hi, double& fx, double& fy, double& fz, int& sx, int& sy, int& sz) {
-  bool ch = false;
-  sx = sy = sz = 0;
-  if (fz > hi) { fz = hi; sz = 1; ch = true; }
-  else if (fz < lo) { fz = lo; sz = -1; ch = true; }
-  double m = mu * fz;
-  if (fx > m) { fx = m; sx = 1; ch = true; }
-  else if (fx < -m) { fx = -m; sx = -1; ch = true; }
-  if (fy > m) { fy = m; sy = 1; ch = true; }
-  else if (fy < -m) { fy = -m; sy = -1; ch = true; }
-  return ch;
+  const bool zu = fz > hi, zl = fz < lo;
+  fz = zu ? hi : (zl ? lo : fz);
+  sz = (int)zu - (int)zl;
+  const double m = mu * fz;
+  const bool xu = fx > m, xl = fx < -m;
+  fx = xu ? m : (xl ? -m : fx);
+  sx = (int)xu - (int)xl;
+  const bool yu = fy > m, yl = fy < -m;
+  fy = yu ? m : (yl ? -m : fy);
+  sy = (int)yu - (int)yl;
+  return zu | zl | xu | xl | yu | yl;
 }
 
-// Keeps the smallest ratio num/den (den > 0) without dividing.
-struct Ratio {
-  double num, den;
-  int code;  // foot*8 + axis*2 + (sign>0), -1 = none
-};
-QC_DEV void ratio_try(Ratio& best, double slack, double nd, int code) {
-  if (nd > 1e-14) {
-    double s = slack > 0.0 ? slack : 0.0;
-    if (s * best.den < best.num * nd) { best.num = s; best.den = nd; best.code = code; }
-  }
+// A (value, 5-bit code) pair packed into one double: the code replaces the 5
+// lowest mantissa bits (relative perturbation 2^-47), so a plain v_min_f64
+// tree yields arg-min and min together, without compare/select chains.
+QC_DEV double tag(double v, int code) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  return __longlong_as_double((long long)((b & ~31ull) | (unsigned long long)code));
+}
+QC_DEV int tag_code(double v) { return (int)(__double_as_longlong(v) & 31ll); }
+
+// Step-length candidate of one face: slack / nd if the face can block
+// (nd > eps and slack < nd, both tested exactly), +BIG otherwise.  The ratio
+// itself only ranks candidates, so the 2^-23-accurate v_rcp_f64 is enough.
+#define QC_BIG 1.0e300
+QC_DEV double step_cand(double slack, double nd, int code) {
+  const double s = fmax(slack, 0.0);
+  const bool can = (nd > 1e-14) & (s < nd);
+  const double a = s * __builtin_amdgcn_rcp(nd);
+  return tag(can ? a : QC_BIG, code);
 }
 
 // -------------------------------------------------------------- EQP, diagonal W
@@ -251,7 +261,7 @@ QC_DEV void ratio_try(Ratio& best, double slack, double nd, int code) {
 // 6x6 Cholesky per working-set recalculation; the Hessian Q = 2(A^T S A + W)
 // of BC.cpp:152 is never formed.  The gradient needed for the multipliers is
 // g = Q f + c = 2 (A^T v + W f).
-QC_DEV bool eqp_diagw(const DevParams& P, const Wrench& Wr, const Cube& C, uint32_t stance_mask, double (&f)[12], double (&g)[12]) {
+QC_DEV bool eqp_diagw(const DevParams& P, const Wrench& Wr, const Cube& C, const double (&lo)[4], const double (&hi)[4], double (&f)[12], double (&g)[12]) {
   double M[21];
   // packed lower triangle index r*(r+1)/2 + c
 #define MI(r, c) ((r) * ((r) + 1) / 2 + (c))
@@ -266,11 +276,11 @@ QC_DEV bool eqp_diagw(const DevParams& P, const Wrench& Wr, const Cube& C, uint3
   double q[4][6], ix[4], iy[4], iz[4], fzfix[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    const bool st = (stance_mask >> i) & 1u;
+    const bool st = hi[i] > 0.0;  // swing feet have lo = hi = 0 and never leave f = 0
     const double rx = Wr.r[i][0], ry = Wr.r[i][1], rz = Wr.r[i][2];
     const int sx = C.sx[i], sy = C.sy[i], sz = C.sz[i];
     const double mx = P.mu * (double)sx, my = P.mu * (double)sy;
-    fzfix[i] = st ? (sz > 0 ? P.fzmax : (sz < 0 ? P.fzmin : 0.0)) : 0.0;
+    fzfix[i] = sz > 0 ? hi[i] : (sz < 0 ? lo[i] : 0.0);
     ix[i] = (st && sx == 0) ? P.inv_wx[i] : 0.0;
     iy[i] = (st && sy == 0) ? P.inv_wy[i] : 0.0;
     const int sel = (sx != 0 ? 2 : 0) + (sy != 0 ? 1 : 0);

@@ -1,0 +1,31 @@
+"""Multi-GPU plumbing of the batched balance controller.
+
+The path shards trivially: every robot is independent, so rank r of G owns a
+contiguous slice of the batch axis and there is NO data-path collective.
+torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in
+the CPU tests) is used only for the barrier around the timed region and to
+reduce a handful of counters.
+"""
+from __future__ import annotations
+
+
+def shard_bounds(n, rank, world):
+    """Contiguous shard [lo, hi) of a batch of n robots owned by `rank`."""
+    base, rem = divmod(int(n), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def reduce_counters(dist, wall_s, solved, robots, device=None):
+    """(max wall time over ranks, total solved, total robots).  `dist` is
+    torch.distributed (initialised) or None for a single process."""
+    if dist is None:
+        return float(wall_s), int(solved), int(robots)
+    import torch
+
+    kw = {} if device is None else {"device": device}
+    t = torch.tensor([float(wall_s)], dtype=torch.float64, **kw)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    c = torch.tensor([int(solved), int(robots)], dtype=torch.int64, **kw)
+    dist.all_reduce(c, op=dist.ReduceOp.SUM)
+    return float(t.item()), int(c[0].item()), int(c[1].item())

@@ -1,0 +1,59 @@
+"""CPU, world_size 2, gloo: the N>1 plumbing of bench.py (shard ownership,
+max-over-ranks timing, counter reduction).  No GPU, no data-path collective."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import c_oracle, numpy_restatement as R  # checker standing in for the GPU on CPU
+    from quadruped_control_amd import workloads as W
+    from quadruped_control_amd.sharding import reduce_counters, shard_bounds
+
+    lo, hi = shard_bounds(n, rank, world)
+    batch = W.config5(n=hi - lo, start=lo)
+    grf, status, _ = c_oracle.control_batch(R.cheetah_params(0.6), batch)
+    wall, solved, robots = reduce_counters(dist, 1.0 + rank, int((status == 0).sum()), hi - lo)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (lo, hi, grf))
+    dist.barrier()
+    if rank == 0:
+        q.put((wall, solved, robots, gathered))
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_gloo():
+    n, world = 301, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    wall, solved, robots, gathered = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert wall == 2.0 and robots == n and solved == n
+    gathered.sort(key=lambda t: t[0])
+    assert gathered[0][0] == 0 and gathered[0][1] == gathered[1][0] and gathered[1][1] == n
+    from oracle import c_oracle, numpy_restatement as R
+    from quadruped_control_amd import workloads as W
+
+    full, st, _ = c_oracle.control_batch(R.cheetah_params(0.6), W.config5(n=n, start=0))
+    np.testing.assert_array_equal(np.concatenate([g[2] for g in gathered]), full)

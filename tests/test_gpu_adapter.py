@@ -1,0 +1,16 @@
+"""-m gpu: the C++ BalanceController adapter (include/qc_balance_controller.hpp)."""
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_cpp_adapter(built):
+    exe = os.path.join(os.path.dirname(__file__), "cpp", "adapter_test")
+    assert os.path.exists(exe)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for tag in ("OK kat1", "OK kat3", "OK out_of_range", "OK copy_to_real_t"):
+        assert tag in r.stdout, r.stdout + r.stderr
