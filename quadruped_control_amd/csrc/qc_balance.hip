@@ -160,7 +160,8 @@ __global__ __launch_bounds__(64) void balance_kernel(const DevParams P, const lo
     stance_mask = ((sw & 0xFFu) ? 1u : 0u) | ((sw & 0xFF00u) ? 2u : 0u) | ((sw & 0xFF0000u) ? 4u : 0u) | ((sw & 0xFF000000u) ? 8u : 0u);
   }
 
-  Eqp eqp(P, Wr);
+  extern __shared__ __attribute__((aligned(16))) double qc_lds[];  // dense path: 78 planes x 64 lanes; unused (size 0) otherwise
+  Eqp eqp(P, Wr, qc_lds + threadIdx.x);
 
   Cube C;
 #pragma unroll
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(64) void balance_kernel(const DevParams P, const lo
 }
 
 struct EqpDiagW {
-  QC_DEV EqpDiagW(const DevParams&, const Wrench&) {}
+  QC_DEV EqpDiagW(const DevParams&, const Wrench&, double*) {}
   QC_DEV bool solve(const DevParams& P, const Wrench& Wr, const Cube& C, const double (&lo)[4], const double (&hi)[4], double (&f)[12], double (&g)[12]) {
     return eqp_diagw(P, Wr, C, lo, hi, f, g);
   }
@@ -304,7 +305,11 @@ int qc_create(const qc_params* p, int device, qc_handle** out) {
     for (int j = 0; j < 12; j++)
       if (i != j && p->W[12 * i + j] != 0.0) diag = false;
   }
-  if (!diag) return fail(QC_ERR_INVALID, "qc_create: non-diagonal W not supported yet by this build");
+  for (int i = 0; i < 12; i++)
+    for (int j = 0; j < i; j++)
+      if (std::fabs(p->W[12 * i + j] - p->W[12 * j + i]) > 1e-12 * (p->W[12 * i + i] + p->W[12 * j + j]))
+        return fail(QC_ERR_INVALID, "qc_create: W must be symmetric");
+  if (const char* e = std::getenv("QC_FORCE_DENSE")) if (e[0] == '1') diag = false;  // test/bench knob: dense path on a diagonal W
 
   qc_handle* h = new (std::nothrow) qc_handle();
   if (!h) return fail(QC_ERR_INVALID, "qc_create: out of memory");
@@ -320,6 +325,7 @@ int qc_create(const qc_params* p, int device, qc_handle** out) {
   std::memcpy(d.S, p->S, sizeof(d.S));
   if (!spd_inverse(p->S, 6, d.V)) { delete h; return fail(QC_ERR_INVALID, "qc_create: S must be positive definite"); }
   for (int i = 0; i < 12; i++) d.w[i] = p->W[12 * i + i];
+  std::memcpy(d.W, p->W, sizeof(d.W));
   for (int i = 0; i < 4; i++) {
     d.inv_wx[i] = 1.0 / d.w[3 * i];
     d.inv_wy[i] = 1.0 / d.w[3 * i + 1];
@@ -359,7 +365,11 @@ int qc_control_batch(qc_handle* h, size_t n, const qc_batch_in* in, const uint32
   qc::BatchIn bi{in->Rwb, in->Rwb_d, in->x, in->xdot, in->w, in->x_d, in->xdot_d, in->w_d, in->feet, in->stance};
   qc::BatchOut bo{out->grf_body, out->status, out->active_set, out->iterations};
   const unsigned blocks = (unsigned)((n + 63) / 64);
-  hipLaunchKernelGGL(qc::balance_kernel<qc::EqpDiagW>, dim3(blocks), dim3(64), 0, (hipStream_t)stream, h->dp, (long)n, bi, warm, bo);
+  if (h->diag_w)
+    hipLaunchKernelGGL(qc::balance_kernel<qc::EqpDiagW>, dim3(blocks), dim3(64), 0, (hipStream_t)stream, h->dp, (long)n, bi, warm, bo);
+  else
+    hipLaunchKernelGGL(qc::balance_kernel<qc::EqpDense>, dim3(blocks), dim3(64), 78 * 64 * sizeof(double), (hipStream_t)stream, h->dp,
+                       (long)n, bi, warm, bo);
   QC_HIP(hipGetLastError());
   return QC_OK;
 }

@@ -27,6 +27,7 @@ struct DevParams {
   double S[36];        // wrench weight (general SPD)
   double V[36];        // S^-1 (host-computed), used by the diagW formulation
   double w[12];        // diag(W) (diagW formulation)
+  double W[144];       // full W, row-major (dense formulation)
   double inv_wx[4];    // 1 / w_x per foot
   double inv_wy[4];    // 1 / w_y per foot
   double inv_bz[16];   // [foot][|sx|*2+|sy|] 1 / (w_z + mu^2 (|sx| w_x + |sy| w_y))
@@ -374,5 +375,197 @@ QC_DEV bool eqp_diagw(const DevParams& P, const Wrench& Wr, const Cube& C, const
   }
   return ok;
 }
+
+// ------------------------------------------------------------ EQP, general W
+// Dense formulation for a general SPD W (the API allows any 12x12 SPD W,
+// BC.hpp:77; the reference's own configs use W = w*I and take the diagW path).
+// The Hessian Q = 2(A^T S A + W) (BC.cpp:152) is assembled once per robot and
+// staged in LDS as 78 packed lower-triangle planes of 64 lanes
+// (Qs[k*64 + lane]: consecutive lanes -> consecutive 8-byte words, so every
+// ds_read_b64 / ds_write_b64 is bank-conflict free).  Each working-set
+// recalculation forms the masked reduced Hessian H = T^T Q T + (I - D) in
+// registers (fixed 12x12 shape, identity rows on fixed slots, so indexing stays
+// compile-time), factorises it with an unrolled Cholesky and back-substitutes.
+#define QC_SYM(r, c) ((r) >= (c) ? ((r) * ((r) + 1) / 2 + (c)) : ((c) * ((c) + 1) / 2 + (r)))
+
+struct EqpDense {
+  double* Qs;    // LDS base of this lane: element k at Qs[k * 64]
+  double c[12];  // c = -2 A^T S b (BC.cpp:153)
+
+  QC_DEV double q(int r, int cc) const { return Qs[QC_SYM(r, cc) * 64]; }
+
+  QC_DEV EqpDense(const DevParams& P, const Wrench& Wr, double* lds_lane) : Qs(lds_lane) {
+    double Sb[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      double t = 0.0;
+#pragma unroll
+      for (int m = 0; m < 6; m++) t = __builtin_fma(P.S[6 * k + m], Wr.b[m], t);
+      Sb[k] = t;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const double rx = Wr.r[j][0], ry = Wr.r[j][1], rz = Wr.r[j][2];
+      // SA_j = S [I; [r_j]x]   (6x3)
+      double SA[6][3];
+#pragma unroll
+      for (int k = 0; k < 6; k++) {
+        SA[k][0] = P.S[6 * k + 0] + P.S[6 * k + 4] * rz - P.S[6 * k + 5] * ry;
+        SA[k][1] = P.S[6 * k + 1] - P.S[6 * k + 3] * rz + P.S[6 * k + 5] * rx;
+        SA[k][2] = P.S[6 * k + 2] + P.S[6 * k + 3] * ry - P.S[6 * k + 4] * rx;
+      }
+      // c_j = -2 A_j^T (S b)
+      c[3 * j + 0] = -2.0 * (Sb[0] + Sb[4] * rz - Sb[5] * ry);
+      c[3 * j + 1] = -2.0 * (Sb[1] - Sb[3] * rz + Sb[5] * rx);
+      c[3 * j + 2] = -2.0 * (Sb[2] + Sb[3] * ry - Sb[4] * rx);
+#pragma unroll
+      for (int i = j; i < 4; i++) {
+        const double ix = Wr.r[i][0], iy = Wr.r[i][1], iz = Wr.r[i][2];
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+          // column b of A_i^T SA_j
+          const double t0 = SA[0][b] + SA[4][b] * iz - SA[5][b] * iy;
+          const double t1 = SA[1][b] - SA[3][b] * iz + SA[5][b] * ix;
+          const double t2 = SA[2][b] + SA[3][b] * iy - SA[4][b] * ix;
+          const double t[3] = {t0, t1, t2};
+#pragma unroll
+          for (int a = 0; a < 3; a++) {
+            const int r = 3 * i + a, cc = 3 * j + b;
+            if (r >= cc) Qs[(r * (r + 1) / 2 + cc) * 64] = 2.0 * (t[a] + P.W[12 * r + cc]);
+          }
+        }
+      }
+    }
+  }
+
+  QC_DEV bool solve(const DevParams& P, const Wrench&, const Cube& C, const double (&lo)[4], const double (&hi)[4],
+                    double (&f)[12], double (&g)[12]) {
+    double ax[4], ay[4], az[4], cx[4], cy[4], mx[4], my[4], fzfix[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const bool st = hi[i] > 0.0;
+      const int sx = C.sx[i], sy = C.sy[i], sz = C.sz[i];
+      ax[i] = (st && sx == 0) ? 1.0 : 0.0;
+      ay[i] = (st && sy == 0) ? 1.0 : 0.0;
+      az[i] = (st && sz == 0) ? 1.0 : 0.0;
+      mx[i] = P.mu * (double)sx;
+      my[i] = P.mu * (double)sy;
+      cx[i] = mx[i] * az[i];
+      cy[i] = my[i] * az[i];
+      fzfix[i] = sz > 0 ? hi[i] : (sz < 0 ? lo[i] : 0.0);
+    }
+    double L[78], gp[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) gp[k] = c[k];
+    // H = T^T Q T (+ identity on fixed slots) and gp = Q p + c, one pass over Q
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+#pragma unroll
+      for (int j = 0; j <= i; j++) {
+        double Qb[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+          for (int b = 0; b < 3; b++) Qb[a][b] = q(3 * i + a, 3 * j + b);
+        // gp_i += Q_ij p_j ; gp_j += Q_ij^T p_i (i != j)
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+          const double t = Qb[a][0] * mx[j] + Qb[a][1] * my[j] + Qb[a][2];
+          gp[3 * i + a] = __builtin_fma(fzfix[j], t, gp[3 * i + a]);
+        }
+        if (i != j) {
+#pragma unroll
+          for (int b = 0; b < 3; b++) {
+            const double t = Qb[0][b] * mx[i] + Qb[1][b] * my[i] + Qb[2][b];
+            gp[3 * j + b] = __builtin_fma(fzfix[i], t, gp[3 * j + b]);
+          }
+        }
+        // X = Q_ij T_j ; H_ij = T_i^T X
+        double X[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+          X[a][0] = Qb[a][0] * ax[j];
+          X[a][1] = Qb[a][1] * ay[j];
+          X[a][2] = Qb[a][0] * cx[j] + Qb[a][1] * cy[j] + Qb[a][2] * az[j];
+        }
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+          const double h0 = ax[i] * X[0][b];
+          const double h1 = ay[i] * X[1][b];
+          const double h2 = cx[i] * X[0][b] + cy[i] * X[1][b] + az[i] * X[2][b];
+          const double h[3] = {h0, h1, h2};
+#pragma unroll
+          for (int a = 0; a < 3; a++) {
+            const int r = 3 * i + a, cc = 3 * j + b;
+            if (r >= cc) L[r * (r + 1) / 2 + cc] = h[a];
+          }
+        }
+      }
+      L[QC_SYM(3 * i + 0, 3 * i + 0)] += 1.0 - ax[i];
+      L[QC_SYM(3 * i + 1, 3 * i + 1)] += 1.0 - ay[i];
+      L[QC_SYM(3 * i + 2, 3 * i + 2)] += 1.0 - az[i];
+    }
+    // rhs = -T^T gp
+    double y[12];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      y[3 * i + 0] = -ax[i] * gp[3 * i];
+      y[3 * i + 1] = -ay[i] * gp[3 * i + 1];
+      y[3 * i + 2] = -(cx[i] * gp[3 * i] + cy[i] * gp[3 * i + 1] + az[i] * gp[3 * i + 2]);
+    }
+    // Cholesky H = L L^T, in place, inverse diagonal
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+      double d = L[QC_SYM(k, k)];
+#pragma unroll
+      for (int m = 0; m < k; m++) d = __builtin_fma(-L[QC_SYM(k, m)], L[QC_SYM(k, m)], d);
+      ok = ok && (d > 0.0);
+      const double rinv = rsqrt_nr(d);
+      L[QC_SYM(k, k)] = rinv;
+#pragma unroll
+      for (int r = k + 1; r < 12; r++) {
+        double t = L[QC_SYM(r, k)];
+#pragma unroll
+        for (int m = 0; m < k; m++) t = __builtin_fma(-L[QC_SYM(r, m)], L[QC_SYM(k, m)], t);
+        L[QC_SYM(r, k)] = t * rinv;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+      double t = y[k];
+#pragma unroll
+      for (int m = 0; m < k; m++) t = __builtin_fma(-L[QC_SYM(k, m)], y[m], t);
+      y[k] = t * L[QC_SYM(k, k)];
+    }
+#pragma unroll
+    for (int k = 11; k >= 0; k--) {
+      double t = y[k];
+#pragma unroll
+      for (int m = k + 1; m < 12; m++) t = __builtin_fma(-L[QC_SYM(m, k)], y[m], t);
+      y[k] = t * L[QC_SYM(k, k)];
+    }
+    // f = T y + p
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const double fz = __builtin_fma(az[i], y[3 * i + 2], fzfix[i]);
+      f[3 * i + 2] = fz;
+      f[3 * i + 0] = __builtin_fma(ax[i], y[3 * i], mx[i] * fz);
+      f[3 * i + 1] = __builtin_fma(ay[i], y[3 * i + 1], my[i] * fz);
+    }
+    // g = Q f + c
+#pragma unroll
+    for (int k = 0; k < 12; k++) g[k] = c[k];
+#pragma unroll
+    for (int r = 0; r < 12; r++)
+#pragma unroll
+      for (int cc = 0; cc <= r; cc++) {
+        const double v = Qs[(r * (r + 1) / 2 + cc) * 64];
+        g[r] = __builtin_fma(v, f[cc], g[r]);
+        if (r != cc) g[cc] = __builtin_fma(v, f[r], g[cc]);
+      }
+    return ok;
+  }
+};
 
 }  // namespace qc

@@ -178,3 +178,40 @@ def test_general_S_and_per_axis_W(q):
     assert (o["status"] == 0).all() and (st == 0).all()
     scale = np.maximum(1.0, np.abs(ref).max(axis=1, keepdims=True))
     assert np.max(np.abs(o["grf_body"] - ref) / scale) < 1e-6
+
+
+def test_dense_W_path(q, monkeypatch):
+    """general (non-diagonal) SPD W -> dense 12x12 formulation; also force the
+    dense kernel on the reference's diagonal W and compare both ways."""
+    from oracle import c_oracle as O
+    from quadruped_control_amd import workloads as W
+
+    rng = np.random.default_rng(11)
+    b = W.config3(4096)
+    # (a) diagonal W through the dense kernel == oracle == diagW kernel
+    P = q.cheetah_params(0.6)
+    ref, st, _ = O.control_batch(P, b, threads=8)
+    monkeypatch.setenv("QC_FORCE_DENSE", "1")
+    dense = q.BalanceController.from_params(P)
+    assert dense.kernel_name == "dense-12x12"
+    od = dense.control_batch_host(b, want_iterations=True)
+    monkeypatch.delenv("QC_FORCE_DENSE")
+    diag = q.BalanceController.from_params(P)
+    assert diag.kernel_name == "diagW-6x6"
+    og = diag.control_batch_host(b)
+    scale = np.maximum(1.0, np.abs(ref).max(axis=1, keepdims=True))
+    assert (od["status"] == 0).all()
+    assert np.max(np.abs(od["grf_body"] - ref) / scale) < 1e-6
+    assert np.max(np.abs(od["grf_body"] - og["grf_body"]) / scale) < 1e-6
+    # (b) coupled W
+    A = rng.normal(size=(12, 12))
+    P2 = dict(P)
+    P2["W"] = 1e-5 * (np.eye(12) + 0.2 * (A @ A.T) / 12.0)
+    P2["W"] = 0.5 * (P2["W"] + P2["W"].T)
+    ctl = q.BalanceController.from_params(P2)
+    assert ctl.kernel_name == "dense-12x12"
+    o = ctl.control_batch_host(b)
+    ref2, st2, _ = O.control_batch(P2, b, threads=8)
+    assert (o["status"] == 0).all() and (st2 == 0).all()
+    scale2 = np.maximum(1.0, np.abs(ref2).max(axis=1, keepdims=True))
+    assert np.max(np.abs(o["grf_body"] - ref2) / scale2) < 1e-6
