@@ -101,6 +101,7 @@ inline mat eye(unsigned int r, unsigned int c)
 }
 #endif  // QC_HAVE_ARMADILLO
 
+#ifndef QC_USE_REFERENCE_TYPES  // define it when the reference's own types.hpp / gait.hpp are also included
 /** @brief Leg state in gait (types.hpp:91-95) */
 enum LegState
 {
@@ -124,6 +125,8 @@ inline GaitMap make_stance_gait()
   gait_map.emplace("FR", std::make_pair(LegState::stance, 0.0));
   return gait_map;
 }
+
+#endif  // QC_USE_REFERENCE_TYPES
 
 typedef double real_t;  // qpOASES::real_t in the reference (balance_controller.hpp:29)
 
