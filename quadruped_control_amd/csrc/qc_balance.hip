@@ -20,57 +20,33 @@ namespace qc {
 
 // ------------------------------------------------------------------ the kernel
 // One lane = one robot.  Primal active-set method on the per-foot cube states:
-//   start   f^ = EQP(S0)  (S0 = no active face, or the warm-start word);
-//           f = clamp(f^); if nothing was clamped f^ is feasible.
-//   iterate f^ = EQP(S);  step f -> f^ until the first blocking face (add it),
-//           or, after a full step, drop the face with the most negative
-//           multiplier; stop when all multipliers are >= 0 (KKT).
+//   fresh lane   f^ = EQP(S0)  (S0 = no active face, or the warm-start word);
+//                f = clamp(f^); if nothing was clamped f^ is feasible.
+//   afterwards   f^ = EQP(S);  step f -> f^ until the first blocking face (add
+//                it), or, after a full step, drop the face with the most
+//                negative multiplier; stop when all multipliers are >= 0 (KKT).
 // The QP is strictly convex (W > 0), so the KKT point is THE minimiser qpOASES
 // returns in the reference (BC.cpp:177-210).
-// Per-lane solver state.  All lanes of a wave execute the same working-set
-// recalculation in lockstep; everything below is straight-line, select-based
-// code (no per-lane branches) so the only divergence cost is the iteration
-// count of the slowest lane.
+//
+// A wavefront owns a contiguous chunk of robots and walks through it: all 64
+// lanes execute the same working-set recalculation in lockstep (straight-line,
+// select-based code, no per-lane branches); lanes whose robot has converged
+// park their result and, once `refill_t` lanes are parked, the wave flushes
+// their outputs and hands them the next robots of the chunk.  This keeps the
+// lanes busy although robots need between 1 and ~20 recalculations.
 template <class Eqp>
-struct LaneState {
-  const DevParams& P;
-  const Wrench& Wr;
-  Eqp& eqp;
-  Cube& C;
-  double lo[4], hi[4];  // per-foot fz bounds; (0,0) pins a swing foot to f = 0
+struct Lane {
+  Wrench Wr;
+  Cube C;
   double f[12];
-  int status = QC_MAX_ITER;
-  int iters = 0;
-  bool done = false;
-
-  // first working-set recalculation: f = clamp(EQP(S0))
-  QC_DEV void first() {
-    double fh[12], g[12];
-    iters = 1;
-    const bool ok = eqp.solve(P, Wr, C, lo, hi, fh, g);
-    bool changed = false;
-    Cube Cc;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      f[3 * i] = fh[3 * i]; f[3 * i + 1] = fh[3 * i + 1]; f[3 * i + 2] = fh[3 * i + 2];
-      changed |= clamp_foot(P.mu, lo[i], hi[i], f[3 * i], f[3 * i + 1], f[3 * i + 2], Cc.sx[i], Cc.sy[i], Cc.sz[i]);
-    }
-    // f^ feasible: it is the minimiser on the start face -> multiplier test
-    int wcode;
-    const bool opt = multipliers_ok(g, wcode);
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      C.sx[i] = changed ? Cc.sx[i] : ((wcode == 3 * i + 0) ? 0 : C.sx[i]);
-      C.sy[i] = changed ? Cc.sy[i] : ((wcode == 3 * i + 1) ? 0 : C.sy[i]);
-      C.sz[i] = changed ? Cc.sz[i] : ((wcode == 3 * i + 2) ? 0 : C.sz[i]);
-    }
-    if (!ok) { status = QC_NOT_PD; done = true; }
-    else if (!changed && opt) { status = QC_SOLVED; done = true; }
-  }
+  long idx;
+  uint32_t stance_mask;
+  int status, iters;
+  bool have_f;
 
   // multiplier test on the current face: true if all active faces have
   // lambda >= -tol; otherwise wcode = 3*foot+axis of the most negative one.
-  QC_DEV bool multipliers_ok(const double (&g)[12], int& wcode) const {
+  QC_DEV bool multipliers_ok(CParams& P, const double (&g)[12], int& wcode) const {
     double gs = 1.0;
 #pragma unroll
     for (int k = 0; k < 12; k++) gs = fmax(gs, fabs(g[k]));
@@ -94,12 +70,24 @@ struct LaneState {
     return ok;
   }
 
-  // one working-set recalculation from a feasible f
-  QC_DEV void step() {
+  // one working-set recalculation; returns true when the robot is finished
+  QC_DEV bool iterate(CParams& P, Eqp& eqp) {
     double fh[12], g[12];
     iters++;
-    const bool ok = eqp.solve(P, Wr, C, lo, hi, fh, g);
-    // ratio test over the faces outside the working set (tree min, code in the low bits)
+    const bool pd = eqp.solve(P, Wr, C, stance_mask, fh, g);
+    const bool fresh = !have_f;
+    have_f = true;
+    // (a) fresh lane: clamp f^ into the frusta
+    double fc[12];
+    Cube Cc;
+    bool changed = false;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      fc[3 * i] = fh[3 * i]; fc[3 * i + 1] = fh[3 * i + 1]; fc[3 * i + 2] = fh[3 * i + 2];
+      changed |= clamp_foot(P.mu, foot_lo(P, stance_mask, i), foot_hi(P, stance_mask, i), fc[3 * i], fc[3 * i + 1], fc[3 * i + 2],
+                            Cc.sx[i], Cc.sy[i], Cc.sz[i]);
+    }
+    // (b) otherwise: ratio test over the faces outside the working set (tree min, face code in the low bits)
     double cand[24];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -107,12 +95,12 @@ struct LaneState {
       const double dx = fh[3 * i] - fx, dy = fh[3 * i + 1] - fy, dz = fh[3 * i + 2] - fz;
       const double m = P.mu * fz, md = P.mu * dz;
       const bool zf = C.sz[i] == 0, xf = C.sx[i] == 0, yf = C.sy[i] == 0;
-      cand[6 * i + 0] = step_cand(m + fx, xf ? -dx - md : 0.0, 6 * i + 0);  // X-
-      cand[6 * i + 1] = step_cand(m - fx, xf ? dx - md : 0.0, 6 * i + 1);   // X+
-      cand[6 * i + 2] = step_cand(m + fy, yf ? -dy - md : 0.0, 6 * i + 2);  // Y-
-      cand[6 * i + 3] = step_cand(m - fy, yf ? dy - md : 0.0, 6 * i + 3);   // Y+
-      cand[6 * i + 4] = step_cand(fz - lo[i], zf ? -dz : 0.0, 6 * i + 4);   // Z-
-      cand[6 * i + 5] = step_cand(hi[i] - fz, zf ? dz : 0.0, 6 * i + 5);    // Z+
+      cand[6 * i + 0] = step_cand(xf, m + fx, -dx - md, 6 * i + 0);                            // X-
+      cand[6 * i + 1] = step_cand(xf, m - fx, dx - md, 6 * i + 1);                             // X+
+      cand[6 * i + 2] = step_cand(yf, m + fy, -dy - md, 6 * i + 2);                            // Y-
+      cand[6 * i + 3] = step_cand(yf, m - fy, dy - md, 6 * i + 3);                             // Y+
+      cand[6 * i + 4] = step_cand(zf, fz - foot_lo(P, stance_mask, i), -dz, 6 * i + 4);        // Z-
+      cand[6 * i + 5] = step_cand(zf, foot_hi(P, stance_mask, i) - fz, dz, 6 * i + 5);         // Z+
     }
 #pragma unroll
     for (int k = 0; k < 12; k++) cand[k] = fmin(cand[k], cand[k + 12]);
@@ -121,107 +109,147 @@ struct LaneState {
 #pragma unroll
     for (int k = 0; k < 3; k++) cand[k] = fmin(cand[k], cand[k + 3]);
     const double amin = fmin(fmin(cand[0], cand[1]), cand[2]);
-    const bool blocked = amin < 1.0e299;
+    const bool blocked = !fresh && (amin < 1.0e299);
     const int bcode = blocked ? tag_code(amin) : -1;
-    const double alpha = fmin(amin, 1.0);
+    // f <- f^ + (1 - alpha)(f - f^): exactly f^ for a full step
+    const double beta = blocked ? 1.0 - fmax(amin, 0.0) : 0.0;
 #pragma unroll
-    for (int k = 0; k < 12; k++) f[k] = blocked ? __builtin_fma(alpha, fh[k] - f[k], f[k]) : fh[k];
-    // multiplier test (meaningful after a full step only)
+    for (int k = 0; k < 12; k++) f[k] = fresh ? fc[k] : __builtin_fma(beta, f[k] - fh[k], fh[k]);
+    // multiplier test, meaningful when f landed on f^
+    const bool at_fh = fresh ? !changed : !blocked;
     int wcode;
-    const bool opt = multipliers_ok(g, wcode);
-    if (blocked) wcode = -1;
+    const bool opt = multipliers_ok(P, g, wcode);
+    if (!at_fh) wcode = -1;
+    const bool take_clamp = fresh && changed;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       int sx = C.sx[i], sy = C.sy[i], sz = C.sz[i];
       sx = (bcode == 6 * i + 0) ? -1 : ((bcode == 6 * i + 1) ? 1 : ((wcode == 3 * i + 0) ? 0 : sx));
       sy = (bcode == 6 * i + 2) ? -1 : ((bcode == 6 * i + 3) ? 1 : ((wcode == 3 * i + 1) ? 0 : sy));
       sz = (bcode == 6 * i + 4) ? -1 : ((bcode == 6 * i + 5) ? 1 : ((wcode == 3 * i + 2) ? 0 : sz));
-      C.sx[i] = sx; C.sy[i] = sy; C.sz[i] = sz;
+      C.sx[i] = take_clamp ? Cc.sx[i] : sx;
+      C.sy[i] = take_clamp ? Cc.sy[i] : sy;
+      C.sz[i] = take_clamp ? Cc.sz[i] : sz;
     }
-    if (!ok) { status = QC_NOT_PD; done = true; }
-    else if (!blocked && opt) { status = QC_SOLVED; done = true; }
+    if (!pd) { status = QC_NOT_PD; return true; }
+    if (at_fh && opt) { status = QC_SOLVED; return true; }
+    return iters >= P.max_iter;  // status stays QC_MAX_ITER
+  }
+
+  // fetch robot `robot` into this lane
+  QC_DEV void load(CParams& P, const BatchIn& in, const uint32_t* __restrict__ warm, long robot) {
+    idx = robot;
+    double R[9];
+    build_wrench(P, in, robot, R, Wr);
+    stance_mask = 0xFu;  // make_stance_gait(), gait.cpp:24-34
+    if (in.stance) {
+      const uint32_t sw = *reinterpret_cast<const uint32_t*>(in.stance + 4 * robot);
+      stance_mask = ((sw & 0xFFu) ? 1u : 0u) | ((sw & 0xFF00u) ? 2u : 0u) | ((sw & 0xFF0000u) ? 4u : 0u) | ((sw & 0xFF000000u) ? 8u : 0u);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) C.sx[i] = C.sy[i] = C.sz[i] = 0;
+    if (warm) {
+      const uint32_t wv = warm[robot];
+      if (wv & 0x80000000u) decode_states(wv, C);
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        if (!((stance_mask >> i) & 1u)) C.sx[i] = C.sy[i] = C.sz[i] = 0;
+    }
+#pragma unroll
+    for (int k = 0; k < 12; k++) f[k] = 0.0;
+    status = QC_MAX_ITER;
+    iters = 0;
+    have_f = false;
+    // non-finite inputs poison b, r or R: report them as QC_NOT_PD instead of iterating on NaNs
+    double fin = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) fin = __builtin_fma(Wr.b[k], 0.0, fin);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int k = 0; k < 3; k++) fin = __builtin_fma(Wr.r[i][k], 0.0, fin);
+#pragma unroll
+    for (int k = 0; k < 9; k++) fin = __builtin_fma(R[k], 0.0, fin);
+    if (!(fin == 0.0)) {  // make every later quantity finite; iterate() then reports NOT_PD through the flag below
+#pragma unroll
+      for (int k = 0; k < 6; k++) Wr.b[k] = 0.0;
+#pragma unroll
+      for (int i = 0; i < 4; i++) Wr.r[i][0] = Wr.r[i][1] = Wr.r[i][2] = 0.0;
+      stance_mask |= 0x100u;  // bit 8: poisoned input
+    }
+  }
+
+  // output transform, BC.cpp:218-232: fb = -Rwb^T fw for stance legs (Rwb re-read: cheaper than 18 live VGPRs)
+  QC_DEV void store(const BatchIn& in, const BatchOut& out) const {
+    const double* Rp = in.Rwb + 9 * idx;
+    double R[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) R[k] = Rp[k];
+    const int st_out = (stance_mask & 0x100u) ? (int)QC_NOT_PD : status;
+    double* o = out.grf_body + 12 * idx;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const bool st = ((stance_mask >> i) & 1u) && st_out == QC_SOLVED;
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        const double v = -(R[r] * f[3 * i] + R[3 + r] * f[3 * i + 1] + R[6 + r] * f[3 * i + 2]);
+        o[3 * i + r] = st ? v : 0.0;
+      }
+    }
+    out.status[idx] = st_out;
+    if (out.active_set) out.active_set[idx] = encode_states(C);
+    if (out.iterations) out.iterations[idx] = iters;
   }
 };
 
-template <class Eqp>
-__global__ __launch_bounds__(64) void balance_kernel(const DevParams P, const long n, const BatchIn in,
-                                                     const uint32_t* __restrict__ warm, const BatchOut out) {
-  const long gid = (long)blockIdx.x * 64 + threadIdx.x;
-  const bool valid = gid < n;
-  const long idx = valid ? gid : n - 1;  // tail lanes recompute the last robot, never store
-
-  double R[9];
-  Wrench Wr;
-  build_wrench(P, in, idx, R, Wr);
-
-  uint32_t stance_mask = 0xFu;  // make_stance_gait(), gait.cpp:24-34
-  if (in.stance) {
-    const uint32_t sw = *reinterpret_cast<const uint32_t*>(in.stance + 4 * idx);
-    stance_mask = ((sw & 0xFFu) ? 1u : 0u) | ((sw & 0xFF00u) ? 2u : 0u) | ((sw & 0xFF0000u) ? 4u : 0u) | ((sw & 0xFF000000u) ? 8u : 0u);
-  }
-
+template <class Eqp, int MIN_WAVES_PER_SIMD>
+__global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const DevParams* __restrict__ Pg, const long n, const BatchIn in,
+                                                        const uint32_t* __restrict__ warm, const BatchOut out, const long chunk,
+                                                        const int refill_t) {
   extern __shared__ __attribute__((aligned(16))) double qc_lds[];  // dense path: 78 planes x 64 lanes; unused (size 0) otherwise
-  Eqp eqp(P, Wr, qc_lds + threadIdx.x);
-
-  Cube C;
-#pragma unroll
-  for (int i = 0; i < 4; i++) C.sx[i] = C.sy[i] = C.sz[i] = 0;
-  if (warm) {
-    const uint32_t wv = warm[idx];
-    if (wv & 0x80000000u) decode_states(wv, C);
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-      if (!((stance_mask >> i) & 1u)) C.sx[i] = C.sy[i] = C.sz[i] = 0;
-  }
-
-  LaneState<Eqp> L{P, Wr, eqp, C};
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const bool st = (stance_mask >> i) & 1u;
-    L.lo[i] = st ? P.fzmin : 0.0;
-    L.hi[i] = st ? P.fzmax : 0.0;
-  }
-  // non-finite inputs poison b or r: report them as QC_NOT_PD instead of iterating on NaNs
-  double fin = 0.0;
-#pragma unroll
-  for (int k = 0; k < 6; k++) fin = __builtin_fma(Wr.b[k], 0.0, fin);
-#pragma unroll
-  for (int i = 0; i < 4; i++)
-#pragma unroll
-    for (int k = 0; k < 3; k++) fin = __builtin_fma(Wr.r[i][k], 0.0, fin);
-#pragma unroll
-  for (int k = 0; k < 9; k++) fin = __builtin_fma(R[k], 0.0, fin);
-  L.first();
-  if (!(fin == 0.0)) { L.status = QC_NOT_PD; L.done = true; }
+  long cursor = (long)blockIdx.x * chunk;  // wave-uniform
+  const long end = cursor + chunk < n ? cursor + chunk : n;
+  Lane<Eqp> L;
+  L.idx = -1;
+  Eqp eqp(qc_lds + threadIdx.x);
+  bool busy = false;     // lane holds an unfinished robot
+  bool parked = false;   // lane holds a finished robot whose outputs are not stored yet
   for (;;) {
-    if (!L.done && L.iters >= P.max_iter) L.done = true;  // status stays QC_MAX_ITER
-    if (__builtin_amdgcn_ballot_w64(!L.done) == 0) break;  // wave-uniform exit
-    if (!L.done) L.step();
-  }
-  const int status = L.status, iters = L.iters;
-  const double(&f)[12] = L.f;
-
-  if (!valid) return;
-  // output transform, BC.cpp:218-232: fb = -Rwb^T fw for stance legs
-  double* o = out.grf_body + 12 * idx;
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const bool st = ((stance_mask >> i) & 1u) && status == QC_SOLVED;
-#pragma unroll
-    for (int r = 0; r < 3; r++) {
-      const double v = -(R[r] * f[3 * i] + R[3 + r] * f[3 * i + 1] + R[6 + r] * f[3 * i + 2]);
-      o[3 * i + r] = st ? v : 0.0;
+    const unsigned long long busy_mask = __builtin_amdgcn_ballot_w64(busy);
+    const int n_free = 64 - __builtin_popcountll(busy_mask);
+    const long remaining = end - cursor;
+    const bool refill = remaining > 0 && (n_free >= refill_t || busy_mask == 0);
+    if (refill || busy_mask == 0) {
+      if (parked) { L.store(in, out); parked = false; }
+    }
+    if (refill) {
+      const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(~busy_mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)~busy_mask, 0));
+      if (!busy && rank < remaining) {
+        CParams& P = *QC_PARAMS_HERE(Pg);
+        L.load(P, in, warm, cursor + rank);
+        eqp.setup(P, L.Wr);
+        busy = true;
+      }
+      cursor += n_free < remaining ? n_free : remaining;
+      continue;
+    }
+    if (busy_mask == 0) break;
+    if (busy) {
+      asm volatile("; QC_ITER_BEGIN");
+      CParams& P = *QC_PARAMS_HERE(Pg);
+      const bool fin = L.iterate(P, eqp);
+      asm volatile("; QC_ITER_END");
+      if (fin) { busy = false; parked = true; }
     }
   }
-  out.status[idx] = status;
-  if (out.active_set) out.active_set[idx] = encode_states(C);
-  if (out.iterations) out.iterations[idx] = iters;
 }
 
+template <bool UNIFORM>
 struct EqpDiagW {
-  QC_DEV EqpDiagW(const DevParams&, const Wrench&, double*) {}
-  QC_DEV bool solve(const DevParams& P, const Wrench& Wr, const Cube& C, const double (&lo)[4], const double (&hi)[4], double (&f)[12], double (&g)[12]) {
-    return eqp_diagw(P, Wr, C, lo, hi, f, g);
+  QC_DEV explicit EqpDiagW(double*) {}
+  QC_DEV void setup(CParams&, const Wrench&) {}
+  QC_DEV bool solve(CParams& P, const Wrench& Wr, const Cube& C, uint32_t stance_mask, double (&f)[12], double (&g)[12]) {
+    return eqp_diagw<UNIFORM>(P, Wr, C, stance_mask, f, g);
   }
 };
 
@@ -231,7 +259,12 @@ struct EqpDiagW {
 struct qc_handle {
   int device;
   qc::DevParams dp;
-  bool diag_w;
+  qc::DevParams* d_params;  // device copy of dp (immutable after qc_create)
+  bool diag_w;   // W diagonal -> 6x6 formulation
+  bool uniform;  // additionally S diagonal and W = w*I -> scalar-constant specialisation
+  int wave_slots;       // CUs x 4 SIMDs x resident waves per SIMD
+  int refill_t;         // parked lanes that trigger a refill
+  long chunk_override;  // development knob (QC_CHUNK)
   // staging buffers for the host-pointer entry points
   void* stage;
   size_t stage_bytes;
@@ -284,7 +317,10 @@ extern "C" {
 
 const char* qc_last_error(void) { return g_err.c_str(); }
 int qc_abi_version(void) { return QC_ABI_VERSION; }
-const char* qc_kernel_name(const qc_handle* h) { return h ? (h->diag_w ? "diagW-6x6" : "dense-12x12") : ""; }
+const char* qc_kernel_name(const qc_handle* h) {
+  if (!h) return "";
+  return h->diag_w ? (h->uniform ? "diagW-6x6-uniform" : "diagW-6x6") : "dense-12x12";
+}
 
 int qc_create(const qc_params* p, int device, qc_handle** out) {
   if (!p || !out) return fail(QC_ERR_INVALID, "qc_create: null argument");
@@ -318,6 +354,7 @@ int qc_create(const qc_params* p, int device, qc_handle** out) {
   h->stage = nullptr;
   h->stage_bytes = 0;
   h->stream = nullptr;
+  h->d_params = nullptr;
   qc::DevParams& d = h->dp;
   std::memset(&d, 0, sizeof(d));
   d.mu = p->mu; d.mass = p->mass; d.fzmin = p->fzmin; d.fzmax = p->fzmax;
@@ -333,6 +370,18 @@ int qc_create(const qc_params* p, int device, qc_handle** out) {
       for (int b = 0; b < 2; b++)
         d.inv_bz[4 * i + 2 * a + b] = 1.0 / (d.w[3 * i + 2] + p->mu * p->mu * (a * d.w[3 * i] + b * d.w[3 * i + 1]));
   }
+  bool uni = diag;
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j < 6; j++)
+      if (i != j && p->S[6 * i + j] != 0.0) uni = false;
+  for (int i = 1; i < 12; i++)
+    if (p->W[12 * i + i] != p->W[0]) uni = false;
+  if (const char* e = std::getenv("QC_FORCE_GENERAL")) if (e[0] == '1') uni = false;  // test knob
+  h->uniform = uni;
+  for (int i = 0; i < 6; i++) d.Vd[i] = d.V[6 * i + i];
+  d.w_u = p->W[0];
+  d.inv_w_u = 1.0 / p->W[0];
+  for (int k = 0; k < 3; k++) d.inv_bz_u[k] = 1.0 / (p->W[0] * (1.0 + p->mu * p->mu * k));
   std::memcpy(d.kff, p->kff, sizeof(d.kff));
   std::memcpy(d.kp_p, p->kp_p, sizeof(d.kp_p));
   std::memcpy(d.kd_p, p->kd_p, sizeof(d.kd_p));
@@ -341,16 +390,28 @@ int qc_create(const qc_params* p, int device, qc_handle** out) {
   d.tol_d = 1e-12;  // relative to 1+|grad|_inf: W ~ 1e-5 makes the primal very sensitive to a wrongly kept weakly-active face
   if (const char* e = std::getenv("QC_TOL_D")) d.tol_d = std::atof(e);  // development knob
   d.max_iter = p->max_iter > 0 ? p->max_iter : 200;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete h; return fail(QC_ERR_HIP, "qc_create: hipGetDeviceProperties failed"); }
+  h->wave_slots = prop.multiProcessorCount * 4 * (h->diag_w ? 2 : 1);
+  h->refill_t = 16;
+  h->chunk_override = 0;
+  if (const char* e = std::getenv("QC_REFILL_T")) h->refill_t = std::atoi(e);    // development knobs
+  if (const char* e = std::getenv("QC_CHUNK")) h->chunk_override = std::atol(e);
+  if (const char* e = std::getenv("QC_WAVE_SLOTS")) h->wave_slots = std::atoi(e);
+  if (hipSetDevice(device) != hipSuccess || hipMalloc((void**)&h->d_params, sizeof(qc::DevParams)) != hipSuccess ||
+      hipMemcpy(h->d_params, &h->dp, sizeof(qc::DevParams), hipMemcpyHostToDevice) != hipSuccess) {
+    delete h;
+    return fail(QC_ERR_HIP, "qc_create: could not upload the controller constants");
+  }
   *out = h;
   return QC_OK;
 }
 
 void qc_destroy(qc_handle* h) {
   if (!h) return;
-  if (h->stage) {
-    (void)hipSetDevice(h->device);
-    (void)hipFree(h->stage);
-  }
+  (void)hipSetDevice(h->device);
+  if (h->d_params) (void)hipFree(h->d_params);
+  if (h->stage) (void)hipFree(h->stage);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -364,12 +425,21 @@ int qc_control_batch(qc_handle* h, size_t n, const qc_batch_in* in, const uint32
   QC_HIP(hipSetDevice(h->device));
   qc::BatchIn bi{in->Rwb, in->Rwb_d, in->x, in->xdot, in->w, in->x_d, in->xdot_d, in->w_d, in->feet, in->stance};
   qc::BatchOut bo{out->grf_body, out->status, out->active_set, out->iterations};
-  const unsigned blocks = (unsigned)((n + 63) / 64);
-  if (h->diag_w)
-    hipLaunchKernelGGL(qc::balance_kernel<qc::EqpDiagW>, dim3(blocks), dim3(64), 0, (hipStream_t)stream, h->dp, (long)n, bi, warm, bo);
+  // One wave per 64-thread block.  Small batches: one fill of <= 64 robots per
+  // wave.  Batches larger than the chip holds at once: persistent waves, each
+  // walking a contiguous chunk with lane refill (qc::balance_kernel).
+  const long slots = (long)h->wave_slots;
+  long chunk = 64;
+  if ((long)n > 64 * slots) chunk = (((long)n + slots - 1) / slots + 15) / 16 * 16;
+  if (h->chunk_override > 0) chunk = h->chunk_override;
+  const unsigned blocks = (unsigned)(((long)n + chunk - 1) / chunk);
+  if (h->diag_w && h->uniform)
+    qc::balance_kernel<qc::EqpDiagW<true>, 2><<<dim3(blocks), dim3(64), 0, (hipStream_t)stream>>>(h->d_params, (long)n, bi, warm, bo, chunk, h->refill_t);
+  else if (h->diag_w)
+    qc::balance_kernel<qc::EqpDiagW<false>, 2><<<dim3(blocks), dim3(64), 0, (hipStream_t)stream>>>(h->d_params, (long)n, bi, warm, bo, chunk, h->refill_t);
   else
-    hipLaunchKernelGGL(qc::balance_kernel<qc::EqpDense>, dim3(blocks), dim3(64), 78 * 64 * sizeof(double), (hipStream_t)stream, h->dp,
-                       (long)n, bi, warm, bo);
+    qc::balance_kernel<qc::EqpDense, 1><<<dim3(blocks), dim3(64), 78 * 64 * sizeof(double), (hipStream_t)stream>>>(h->d_params, (long)n, bi, warm, bo,
+                                                                                                                   chunk, h->refill_t);
   QC_HIP(hipGetLastError());
   return QC_OK;
 }

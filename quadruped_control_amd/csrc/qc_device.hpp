@@ -31,11 +31,29 @@ struct DevParams {
   double inv_wx[4];    // 1 / w_x per foot
   double inv_wy[4];    // 1 / w_y per foot
   double inv_bz[16];   // [foot][|sx|*2+|sy|] 1 / (w_z + mu^2 (|sx| w_x + |sy| w_y))
+  // uniform-weight specialisation (S diagonal, W = w*I: every reference configuration)
+  double Vd[6];        // diag(S^-1)
+  double w_u;          // w
+  double inv_w_u;      // 1 / w
+  double inv_bz_u[3];  // [|sx|+|sy|] 1 / (w (1 + mu^2 k))
   double kff[6], kp_p[3], kd_p[3], kp_w[3], kd_w[3];
   double tol_d;        // relative multiplier tolerance
   int max_iter;
   int pad;
 };
+
+// Device code reads the constants through the CONSTANT address space (scalar
+// loads).  The kernel re-derives the pointer behind an opaque asm before each
+// phase (see QC_PARAMS_HERE) so the ~1.2 KB of constants are fetched where they
+// are used instead of being hoisted out of the persistent loop, which would
+// overflow the 102-SGPR file and spill to VGPR lanes.
+typedef const __attribute__((address_space(4))) DevParams CParams;
+#define QC_PARAMS_HERE(ptr)                 \
+  ({                                       \
+    const DevParams* p_ = (ptr);           \
+    asm volatile("" : "+s"(p_));          \
+    (CParams*)(unsigned long long)p_;      \
+  })
 
 struct BatchIn {
   const double *Rwb, *Rwb_d, *x, *xdot, *w, *x_d, *xdot_d, *w_d, *feet;
@@ -125,7 +143,7 @@ QC_DEV void load9(const double* __restrict__ p, long idx, double (&v)[9]) {
 }
 
 // K0 + K2 + K3 of SURVEY.md 2.2: gather, PD wrench law, SRB dynamics rhs.
-QC_DEV void build_wrench(const DevParams& P, const BatchIn& in, long idx, double (&R)[9], Wrench& W) {
+QC_DEV void build_wrench(CParams& P, const BatchIn& in, long idx, double (&R)[9], Wrench& W) {
   double Rd[9], x[3], xd[3], xdot[3], xdotd[3], w[3], wd[3];
   load9(in.Rwb, idx, R);
   load9(in.Rwb_d, idx, Rd);
@@ -243,16 +261,24 @@ QC_DEV double tag(double v, int code) {
 }
 QC_DEV int tag_code(double v) { return (int)(__double_as_longlong(v) & 31ll); }
 
-// Step-length candidate of one face: slack / nd if the face can block
-// (nd > eps and slack < nd, both tested exactly), +BIG otherwise.  The ratio
-// itself only ranks candidates, so the 2^-23-accurate v_rcp_f64 is enough.
+// Step-length candidate of one face: slack / nd if the face is outside the
+// working set and can block (nd > eps and slack < nd, both tested exactly),
+// +BIG otherwise.  The ratio itself only ranks candidates, so the
+// 2^-23-accurate v_rcp_f64 is enough; a negative slack (face violated by
+// rounding) ranks first and is clipped to a zero-length step by the caller.
 #define QC_BIG 1.0e300
-QC_DEV double step_cand(double slack, double nd, int code) {
-  const double s = fmax(slack, 0.0);
-  const bool can = (nd > 1e-14) & (s < nd);
-  const double a = s * __builtin_amdgcn_rcp(nd);
-  return tag(can ? a : QC_BIG, code);
+QC_DEV double step_cand(bool free_face, double slack, double nd, int code) {
+  const bool can = free_face & (nd > 1e-14) & (slack < nd);
+  const double a = slack * __builtin_amdgcn_rcp(nd);
+  const unsigned long long b = (unsigned long long)__double_as_longlong(a);
+  const unsigned hi = can ? (unsigned)(b >> 32) : 0x7E37E43Cu;  // high word of 1e300
+  const unsigned lo = ((unsigned)b & ~31u) | (unsigned)code;
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
+
+// per-foot fz bounds from the stance bit: a swing foot is pinned to f = 0
+QC_DEV double foot_lo(CParams& P, uint32_t stance_mask, int i) { return ((stance_mask >> i) & 1u) ? P.fzmin : 0.0; }
+QC_DEV double foot_hi(CParams& P, uint32_t stance_mask, int i) { return ((stance_mask >> i) & 1u) ? P.fzmax : 0.0; }
 
 // -------------------------------------------------------------- EQP, diagonal W
 // Equality-constrained subproblem on the current face, 6-dimensional form.
@@ -262,41 +288,65 @@ QC_DEV double step_cand(double slack, double nd, int code) {
 // 6x6 Cholesky per working-set recalculation; the Hessian Q = 2(A^T S A + W)
 // of BC.cpp:152 is never formed.  The gradient needed for the multipliers is
 // g = Q f + c = 2 (A^T v + W f).
-QC_DEV bool eqp_diagw(const DevParams& P, const Wrench& Wr, const Cube& C, const double (&lo)[4], const double (&hi)[4], double (&f)[12], double (&g)[12]) {
+// Face coefficients of one foot for the current cube state.
+struct FootCoef {
+  double mx, my, fzfix, ix, iy, iz;
+};
+// UNIFORM = (S diagonal, W = w*I): a handful of scalar constants instead of
+// ~60, so they all stay in SGPRs (the general form overflows the SGPR file).
+template <bool UNIFORM>
+QC_DEV FootCoef foot_coef(CParams& P, const Cube& C, uint32_t stance_mask, int i) {
+  FootCoef k;
+  const bool st = (stance_mask >> i) & 1u;
+  const int sx = C.sx[i], sy = C.sy[i], sz = C.sz[i];
+  k.mx = P.mu * (double)sx;
+  k.my = P.mu * (double)sy;
+  k.fzfix = st ? (sz > 0 ? P.fzmax : (sz < 0 ? P.fzmin : 0.0)) : 0.0;
+  if (UNIFORM) {
+    k.ix = (st && sx == 0) ? P.inv_w_u : 0.0;
+    k.iy = (st && sy == 0) ? P.inv_w_u : 0.0;
+    const double b1 = sy != 0 ? P.inv_bz_u[2] : P.inv_bz_u[1];
+    const double b0 = sy != 0 ? P.inv_bz_u[1] : P.inv_bz_u[0];
+    k.iz = (st && sz == 0) ? (sx != 0 ? b1 : b0) : 0.0;
+  } else {
+    k.ix = (st && sx == 0) ? P.inv_wx[i] : 0.0;
+    k.iy = (st && sy == 0) ? P.inv_wy[i] : 0.0;
+    const double b0 = sy != 0 ? P.inv_bz[4 * i + 1] : P.inv_bz[4 * i];
+    const double b1 = sy != 0 ? P.inv_bz[4 * i + 3] : P.inv_bz[4 * i + 2];
+    k.iz = (st && sz == 0) ? (sx != 0 ? b1 : b0) : 0.0;
+  }
+  return k;
+}
+
+template <bool UNIFORM>
+QC_DEV bool eqp_diagw(CParams& P, const Wrench& Wr, const Cube& C, uint32_t stance_mask, double (&f)[12], double (&g)[12]) {
   double M[21];
   // packed lower triangle index r*(r+1)/2 + c
 #define MI(r, c) ((r) * ((r) + 1) / 2 + (c))
 #pragma unroll
   for (int r = 0; r < 6; r++)
 #pragma unroll
-    for (int c = 0; c <= r; c++) M[MI(r, c)] = P.V[6 * r + c];
+    for (int c = 0; c <= r; c++) M[MI(r, c)] = UNIFORM ? (r == c ? P.Vd[r] : 0.0) : P.V[6 * r + c];
   double rhs[6];
 #pragma unroll
   for (int k = 0; k < 6; k++) rhs[k] = -Wr.b[k];
 
-  double q[4][6], ix[4], iy[4], iz[4], fzfix[4];
+  // pass 1: accumulate M = S^-1 + sum_i A~_i B_i^-1 A~_i^T and rhs = -(b - A p)
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    const bool st = hi[i] > 0.0;  // swing feet have lo = hi = 0 and never leave f = 0
+    const FootCoef k = foot_coef<UNIFORM>(P, C, stance_mask, i);
     const double rx = Wr.r[i][0], ry = Wr.r[i][1], rz = Wr.r[i][2];
-    const int sx = C.sx[i], sy = C.sy[i], sz = C.sz[i];
-    const double mx = P.mu * (double)sx, my = P.mu * (double)sy;
-    fzfix[i] = sz > 0 ? hi[i] : (sz < 0 ? lo[i] : 0.0);
-    ix[i] = (st && sx == 0) ? P.inv_wx[i] : 0.0;
-    iy[i] = (st && sy == 0) ? P.inv_wy[i] : 0.0;
-    const int sel = (sx != 0 ? 2 : 0) + (sy != 0 ? 1 : 0);
-    const double ibz = sel == 0 ? P.inv_bz[4 * i] : (sel == 1 ? P.inv_bz[4 * i + 1] : (sel == 2 ? P.inv_bz[4 * i + 2] : P.inv_bz[4 * i + 3]));
-    iz[i] = (st && sz == 0) ? ibz : 0.0;
-    q[i][0] = mx; q[i][1] = my; q[i][2] = 1.0;
-    q[i][3] = ry - rz * my;
-    q[i][4] = rz * mx - rx;
-    q[i][5] = rx * my - ry * mx;
+    double q[6];
+    q[0] = k.mx; q[1] = k.my; q[2] = 1.0;
+    q[3] = ry - rz * k.my;
+    q[4] = rz * k.mx - rx;
+    q[5] = rx * k.my - ry * k.mx;
 #pragma unroll
-    for (int k = 0; k < 6; k++) rhs[k] = __builtin_fma(fzfix[i], q[i][k], rhs[k]);
+    for (int c = 0; c < 6; c++) rhs[c] = __builtin_fma(k.fzfix, q[c], rhs[c]);
     // x slot column (1,0,0, 0, rz, -ry)
     {
-      const double t4 = ix[i] * rz, t5 = -ix[i] * ry;
-      M[MI(0, 0)] += ix[i];
+      const double t4 = k.ix * rz, t5 = -k.ix * ry;
+      M[MI(0, 0)] += k.ix;
       M[MI(4, 0)] += t4;
       M[MI(5, 0)] += t5;
       M[MI(4, 4)] = __builtin_fma(t4, rz, M[MI(4, 4)]);
@@ -305,8 +355,8 @@ QC_DEV bool eqp_diagw(const DevParams& P, const Wrench& Wr, const Cube& C, const
     }
     // y slot column (0,1,0, -rz, 0, rx)
     {
-      const double t3 = -iy[i] * rz, t5 = iy[i] * rx;
-      M[MI(1, 1)] += iy[i];
+      const double t3 = -k.iy * rz, t5 = k.iy * rx;
+      M[MI(1, 1)] += k.iy;
       M[MI(3, 1)] += t3;
       M[MI(5, 1)] += t5;
       M[MI(3, 3)] = __builtin_fma(t3, -rz, M[MI(3, 3)]);
@@ -316,9 +366,9 @@ QC_DEV bool eqp_diagw(const DevParams& P, const Wrench& Wr, const Cube& C, const
     // z slot column q
 #pragma unroll
     for (int c = 0; c < 6; c++) {
-      const double tq = iz[i] * q[i][c];
+      const double tq = k.iz * q[c];
 #pragma unroll
-      for (int r = c; r < 6; r++) M[MI(r, c)] = __builtin_fma(q[i][r], tq, M[MI(r, c)]);
+      for (int r = c; r < 6; r++) M[MI(r, c)] = __builtin_fma(q[r], tq, M[MI(r, c)]);
     }
   }
   // Cholesky M = L L^T (in place; diagonal holds 1/L_kk)
@@ -356,22 +406,23 @@ QC_DEV bool eqp_diagw(const DevParams& P, const Wrench& Wr, const Cube& C, const
     v[k] = t * M[MI(k, k)];
   }
 #undef MI
-  // back to forces and gradient
+  // pass 2: forces and gradient (face coefficients recomputed, not kept live
+  // across the factorisation: registers matter more than ~12 selects per foot)
 #pragma unroll
   for (int i = 0; i < 4; i++) {
+    const FootCoef k = foot_coef<UNIFORM>(P, C, stance_mask, i);
     const double rx = Wr.r[i][0], ry = Wr.r[i][1], rz = Wr.r[i][2];
-    const double yx = -ix[i] * (v[0] + rz * v[4] - ry * v[5]);
-    const double yy = -iy[i] * (v[1] - rz * v[3] + rx * v[5]);
-    double qv = 0.0;
-#pragma unroll
-    for (int k = 0; k < 6; k++) qv = __builtin_fma(q[i][k], v[k], qv);
-    const double fz = fzfix[i] - iz[i] * qv;
-    const double fx = __builtin_fma(q[i][0], fz, yx);
-    const double fy = __builtin_fma(q[i][1], fz, yy);
+    const double ax = v[0] + v[4] * rz - v[5] * ry;  // (A_i^T v)_x
+    const double ay = v[1] + v[5] * rx - v[3] * rz;
+    const double az = v[2] + v[3] * ry - v[4] * rx;
+    const double qv = __builtin_fma(k.mx, ax, __builtin_fma(k.my, ay, az));  // q_i . v
+    const double fz = __builtin_fma(-k.iz, qv, k.fzfix);
+    const double fx = __builtin_fma(k.mx, fz, -k.ix * ax);
+    const double fy = __builtin_fma(k.my, fz, -k.iy * ay);
     f[3 * i] = fx; f[3 * i + 1] = fy; f[3 * i + 2] = fz;
-    g[3 * i] = 2.0 * (v[0] + v[4] * rz - v[5] * ry + P.w[3 * i] * fx);
-    g[3 * i + 1] = 2.0 * (v[1] + v[5] * rx - v[3] * rz + P.w[3 * i + 1] * fy);
-    g[3 * i + 2] = 2.0 * (v[2] + v[3] * ry - v[4] * rx + P.w[3 * i + 2] * fz);
+    g[3 * i] = 2.0 * __builtin_fma(UNIFORM ? P.w_u : P.w[3 * i], fx, ax);
+    g[3 * i + 1] = 2.0 * __builtin_fma(UNIFORM ? P.w_u : P.w[3 * i + 1], fy, ay);
+    g[3 * i + 2] = 2.0 * __builtin_fma(UNIFORM ? P.w_u : P.w[3 * i + 2], fz, az);
   }
   return ok;
 }
@@ -394,7 +445,10 @@ struct EqpDense {
 
   QC_DEV double q(int r, int cc) const { return Qs[QC_SYM(r, cc) * 64]; }
 
-  QC_DEV EqpDense(const DevParams& P, const Wrench& Wr, double* lds_lane) : Qs(lds_lane) {
+  QC_DEV explicit EqpDense(double* lds_lane) : Qs(lds_lane) {}
+
+  // assemble Q (into LDS) and c for the robot this lane just fetched
+  QC_DEV void setup(CParams& P, const Wrench& Wr) {
     double Sb[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) {
@@ -438,12 +492,11 @@ struct EqpDense {
     }
   }
 
-  QC_DEV bool solve(const DevParams& P, const Wrench&, const Cube& C, const double (&lo)[4], const double (&hi)[4],
-                    double (&f)[12], double (&g)[12]) {
+  QC_DEV bool solve(CParams& P, const Wrench&, const Cube& C, uint32_t stance_mask, double (&f)[12], double (&g)[12]) {
     double ax[4], ay[4], az[4], cx[4], cy[4], mx[4], my[4], fzfix[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      const bool st = hi[i] > 0.0;
+      const bool st = (stance_mask >> i) & 1u;
       const int sx = C.sx[i], sy = C.sy[i], sz = C.sz[i];
       ax[i] = (st && sx == 0) ? 1.0 : 0.0;
       ay[i] = (st && sy == 0) ? 1.0 : 0.0;
@@ -452,7 +505,7 @@ struct EqpDense {
       my[i] = P.mu * (double)sy;
       cx[i] = mx[i] * az[i];
       cy[i] = my[i] * az[i];
-      fzfix[i] = sz > 0 ? hi[i] : (sz < 0 ? lo[i] : 0.0);
+      fzfix[i] = st ? (sz > 0 ? P.fzmax : (sz < 0 ? P.fzmin : 0.0)) : 0.0;
     }
     double L[78], gp[12];
 #pragma unroll

@@ -173,7 +173,9 @@ def test_general_S_and_per_axis_W(q):
     P["S"] = np.diag([1, 1, 1, 10, 10, 5.0]) + 0.3 * (A @ A.T)
     P["W"] = np.diag(rng.uniform(0.5e-5, 5e-5, 12))
     b = W.config3(2048)
-    o = q.BalanceController.from_params(P).control_batch_host(b)
+    ctl = q.BalanceController.from_params(P)
+    assert ctl.kernel_name == "diagW-6x6"  # general-S / per-axis-W form of the 6x6 path
+    o = ctl.control_batch_host(b)
     ref, st, _ = O.control_batch(P, b, threads=8)
     assert (o["status"] == 0).all() and (st == 0).all()
     scale = np.maximum(1.0, np.abs(ref).max(axis=1, keepdims=True))
@@ -197,7 +199,7 @@ def test_dense_W_path(q, monkeypatch):
     od = dense.control_batch_host(b, want_iterations=True)
     monkeypatch.delenv("QC_FORCE_DENSE")
     diag = q.BalanceController.from_params(P)
-    assert diag.kernel_name == "diagW-6x6"
+    assert diag.kernel_name == "diagW-6x6-uniform"  # S diagonal, W = w*I: scalar-constant specialisation
     og = diag.control_batch_host(b)
     scale = np.maximum(1.0, np.abs(ref).max(axis=1, keepdims=True))
     assert (od["status"] == 0).all()
