@@ -100,6 +100,18 @@ def run_config(ctl, q, cfg, n, start, steps, warmup, dist=None, device=0):
     return dict(wall=wall, event_s=evs, solved=solved, n=n, batch=batch, warm=warm is not None)
 
 
+def host_cores():
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(P, batch, budget_s=4.0):
     """C oracle (oracle/balance_oracle.c: a port of the reference path, NOT
     qpOASES) on the host cores over the same robots; bounded to a few seconds
@@ -109,7 +121,7 @@ def cpu_baseline(P, batch, budget_s=4.0):
     import numpy as np
 
     n_all = batch["x"].shape[0]
-    threads = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    threads = host_cores()
     base = min(n_all, 4096)
     tile = max(1, (256 * threads + base - 1) // base)  # >= 256 robots per thread per call
     sample = {k: np.ascontiguousarray(np.tile(v[:base], (tile, 1))) for k, v in batch.items()}

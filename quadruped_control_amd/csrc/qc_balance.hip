@@ -19,8 +19,9 @@
 namespace qc {
 
 // ------------------------------------------------------------------ the kernel
-// One lane = one robot.  Primal active-set method on the per-foot cube states:
-//   fresh lane   f^ = EQP(S0)  (S0 = no active face, or the warm-start word);
+// A group of G lanes = one robot (qc_device.hpp).  Primal active-set method on
+// the per-foot cube states:
+//   fresh robot  f^ = EQP(S0)  (S0 = no active face, or the warm-start word);
 //                f = clamp(f^); if nothing was clamped f^ is feasible.
 //   afterwards   f^ = EQP(S);  step f -> f^ until the first blocking face (add
 //                it), or, after a full step, drop the face with the most
@@ -28,43 +29,51 @@ namespace qc {
 // The QP is strictly convex (W > 0), so the KKT point is THE minimiser qpOASES
 // returns in the reference (BC.cpp:177-210).
 //
-// A wavefront owns a contiguous chunk of robots and walks through it: all 64
+// A wavefront owns a contiguous chunk of robots and walks through it: all
 // lanes execute the same working-set recalculation in lockstep (straight-line,
-// select-based code, no per-lane branches); lanes whose robot has converged
-// park their result and, once `refill_t` lanes are parked, the wave flushes
+// select-based code, no per-lane branches); groups whose robot has converged
+// park their result and, once `refill_t` groups are parked, the wave flushes
 // their outputs and hands them the next robots of the chunk.  This keeps the
 // lanes busy although robots need between 1 and ~20 recalculations.
 template <class Eqp>
 struct Lane {
-  Wrench Wr;
-  Cube C;
-  double f[12];
+  static constexpr int G = Eqp::G;
+  static constexpr int FPL = 4 / G;  // feet per lane
+  Wrench<FPL> Wr;
+  Cube<FPL> C;
+  double f[3 * FPL];
   long idx;
-  uint32_t stance_mask;
+  uint32_t stance;  // bits 0-3: LegState per foot, bit 8: non-finite input
+  int foot0;        // first foot of this lane
   int status, iters;
   bool have_f;
 
+  QC_DEV double lo(CParams& P, int i) const { return ((stance >> (foot0 + i)) & 1u) ? P.fzmin : 0.0; }
+  QC_DEV double hi(CParams& P, int i) const { return ((stance >> (foot0 + i)) & 1u) ? P.fzmax : 0.0; }
+
   // multiplier test on the current face: true if all active faces have
   // lambda >= -tol; otherwise wcode = 3*foot+axis of the most negative one.
-  QC_DEV bool multipliers_ok(CParams& P, const double (&g)[12], int& wcode) const {
+  QC_DEV bool multipliers_ok(CParams& P, const double (&g)[3 * FPL], int& wcode) const {
     double gs = 1.0;
 #pragma unroll
-    for (int k = 0; k < 12; k++) gs = fmax(gs, fabs(g[k]));
-    double cand[12];
+    for (int k = 0; k < 3 * FPL; k++) gs = fmax(gs, fabs(g[k]));
+    gs = group_max<G>(gs);
+    double cand[3 * FPL];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < FPL; i++) {
       const double lx = -(double)C.sx[i] * g[3 * i];
       const double ly = -(double)C.sy[i] * g[3 * i + 1];
       const double lz = (double)C.sz[i] * (P.mu * (lx + ly) - g[3 * i + 2]);
-      cand[3 * i + 0] = tag(C.sx[i] != 0 ? lx : QC_BIG, 3 * i + 0);
-      cand[3 * i + 1] = tag(C.sy[i] != 0 ? ly : QC_BIG, 3 * i + 1);
-      cand[3 * i + 2] = tag(C.sz[i] != 0 ? lz : QC_BIG, 3 * i + 2);
+      const int c0 = 3 * (foot0 + i);
+      cand[3 * i + 0] = tag(C.sx[i] != 0 ? lx : QC_BIG, c0 + 0);
+      cand[3 * i + 1] = tag(C.sy[i] != 0 ? ly : QC_BIG, c0 + 1);
+      cand[3 * i + 2] = tag(C.sz[i] != 0 ? lz : QC_BIG, c0 + 2);
     }
 #pragma unroll
-    for (int k = 0; k < 6; k++) cand[k] = fmin(cand[k], cand[k + 6]);
+    for (int w = 3 * FPL; w > 1; w = (w + 1) / 2)
 #pragma unroll
-    for (int k = 0; k < 3; k++) cand[k] = fmin(cand[k], cand[k + 3]);
-    const double worst = fmin(fmin(cand[0], cand[1]), cand[2]);
+      for (int k = 0; k < w / 2; k++) cand[k] = fmin(cand[k], cand[k + (w + 1) / 2]);
+    const double worst = group_min<G>(cand[0]);
     const bool ok = !(worst < -P.tol_d * gs);
     wcode = ok ? -1 : tag_code(worst);
     return ok;
@@ -72,49 +81,48 @@ struct Lane {
 
   // one working-set recalculation; returns true when the robot is finished
   QC_DEV bool iterate(CParams& P, Eqp& eqp) {
-    double fh[12], g[12];
+    double fh[3 * FPL], g[3 * FPL];
     iters++;
-    const bool pd = eqp.solve(P, Wr, C, stance_mask, fh, g);
+    const bool pd = eqp.solve(P, Wr, C, stance, foot0, fh, g);
     const bool fresh = !have_f;
     have_f = true;
-    // (a) fresh lane: clamp f^ into the frusta
-    double fc[12];
-    Cube Cc;
-    bool changed = false;
+    // (a) fresh robot: clamp f^ into the frusta
+    double fc[3 * FPL];
+    Cube<FPL> Cc;
+    int ch = 0;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < FPL; i++) {
       fc[3 * i] = fh[3 * i]; fc[3 * i + 1] = fh[3 * i + 1]; fc[3 * i + 2] = fh[3 * i + 2];
-      changed |= clamp_foot(P.mu, foot_lo(P, stance_mask, i), foot_hi(P, stance_mask, i), fc[3 * i], fc[3 * i + 1], fc[3 * i + 2],
-                            Cc.sx[i], Cc.sy[i], Cc.sz[i]);
+      ch |= (int)clamp_foot(P.mu, lo(P, i), hi(P, i), fc[3 * i], fc[3 * i + 1], fc[3 * i + 2], Cc.sx[i], Cc.sy[i], Cc.sz[i]);
     }
+    const bool changed = group_or<G>(ch) != 0;
     // (b) otherwise: ratio test over the faces outside the working set (tree min, face code in the low bits)
-    double cand[24];
+    double cand[6 * FPL];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < FPL; i++) {
       const double fx = f[3 * i], fy = f[3 * i + 1], fz = f[3 * i + 2];
       const double dx = fh[3 * i] - fx, dy = fh[3 * i + 1] - fy, dz = fh[3 * i + 2] - fz;
       const double m = P.mu * fz, md = P.mu * dz;
       const bool zf = C.sz[i] == 0, xf = C.sx[i] == 0, yf = C.sy[i] == 0;
-      cand[6 * i + 0] = step_cand(xf, m + fx, -dx - md, 6 * i + 0);                            // X-
-      cand[6 * i + 1] = step_cand(xf, m - fx, dx - md, 6 * i + 1);                             // X+
-      cand[6 * i + 2] = step_cand(yf, m + fy, -dy - md, 6 * i + 2);                            // Y-
-      cand[6 * i + 3] = step_cand(yf, m - fy, dy - md, 6 * i + 3);                             // Y+
-      cand[6 * i + 4] = step_cand(zf, fz - foot_lo(P, stance_mask, i), -dz, 6 * i + 4);        // Z-
-      cand[6 * i + 5] = step_cand(zf, foot_hi(P, stance_mask, i) - fz, dz, 6 * i + 5);         // Z+
+      const int c0 = 6 * (foot0 + i);
+      cand[6 * i + 0] = step_cand(xf, m + fx, -dx - md, c0 + 0);     // X-
+      cand[6 * i + 1] = step_cand(xf, m - fx, dx - md, c0 + 1);      // X+
+      cand[6 * i + 2] = step_cand(yf, m + fy, -dy - md, c0 + 2);     // Y-
+      cand[6 * i + 3] = step_cand(yf, m - fy, dy - md, c0 + 3);      // Y+
+      cand[6 * i + 4] = step_cand(zf, fz - lo(P, i), -dz, c0 + 4);   // Z-
+      cand[6 * i + 5] = step_cand(zf, hi(P, i) - fz, dz, c0 + 5);    // Z+
     }
 #pragma unroll
-    for (int k = 0; k < 12; k++) cand[k] = fmin(cand[k], cand[k + 12]);
+    for (int w = 6 * FPL; w > 1; w = (w + 1) / 2)
 #pragma unroll
-    for (int k = 0; k < 6; k++) cand[k] = fmin(cand[k], cand[k + 6]);
-#pragma unroll
-    for (int k = 0; k < 3; k++) cand[k] = fmin(cand[k], cand[k + 3]);
-    const double amin = fmin(fmin(cand[0], cand[1]), cand[2]);
+      for (int k = 0; k < w / 2; k++) cand[k] = fmin(cand[k], cand[k + (w + 1) / 2]);
+    const double amin = group_min<G>(cand[0]);
     const bool blocked = !fresh && (amin < 1.0e299);
     const int bcode = blocked ? tag_code(amin) : -1;
     // f <- f^ + (1 - alpha)(f - f^): exactly f^ for a full step
     const double beta = blocked ? 1.0 - fmax(amin, 0.0) : 0.0;
 #pragma unroll
-    for (int k = 0; k < 12; k++) f[k] = fresh ? fc[k] : __builtin_fma(beta, f[k] - fh[k], fh[k]);
+    for (int k = 0; k < 3 * FPL; k++) f[k] = fresh ? fc[k] : __builtin_fma(beta, f[k] - fh[k], fh[k]);
     // multiplier test, meaningful when f landed on f^
     const bool at_fh = fresh ? !changed : !blocked;
     int wcode;
@@ -122,11 +130,12 @@ struct Lane {
     if (!at_fh) wcode = -1;
     const bool take_clamp = fresh && changed;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < FPL; i++) {
       int sx = C.sx[i], sy = C.sy[i], sz = C.sz[i];
-      sx = (bcode == 6 * i + 0) ? -1 : ((bcode == 6 * i + 1) ? 1 : ((wcode == 3 * i + 0) ? 0 : sx));
-      sy = (bcode == 6 * i + 2) ? -1 : ((bcode == 6 * i + 3) ? 1 : ((wcode == 3 * i + 1) ? 0 : sy));
-      sz = (bcode == 6 * i + 4) ? -1 : ((bcode == 6 * i + 5) ? 1 : ((wcode == 3 * i + 2) ? 0 : sz));
+      const int b0 = 6 * (foot0 + i), w0 = 3 * (foot0 + i);
+      sx = (bcode == b0 + 0) ? -1 : ((bcode == b0 + 1) ? 1 : ((wcode == w0 + 0) ? 0 : sx));
+      sy = (bcode == b0 + 2) ? -1 : ((bcode == b0 + 3) ? 1 : ((wcode == w0 + 1) ? 0 : sy));
+      sz = (bcode == b0 + 4) ? -1 : ((bcode == b0 + 5) ? 1 : ((wcode == w0 + 2) ? 0 : sz));
       C.sx[i] = take_clamp ? Cc.sx[i] : sx;
       C.sy[i] = take_clamp ? Cc.sy[i] : sy;
       C.sz[i] = take_clamp ? Cc.sz[i] : sz;
@@ -136,46 +145,44 @@ struct Lane {
     return iters >= P.max_iter;  // status stays QC_MAX_ITER
   }
 
-  // fetch robot `robot` into this lane
-  QC_DEV void load(CParams& P, const BatchIn& in, const uint32_t* __restrict__ warm, long robot) {
+  // fetch robot `robot` into this lane's group
+  QC_DEV void load(CParams& P, const BatchIn& in, const uint32_t* __restrict__ warm, long robot, int member) {
     idx = robot;
-    double R[9];
-    build_wrench(P, in, robot, R, Wr);
-    stance_mask = 0xFu;  // make_stance_gait(), gait.cpp:24-34
+    foot0 = member * FPL;
+    const double fin = build_wrench<FPL>(P, in, robot, foot0, Wr);
+    stance = 0xFu;  // make_stance_gait(), gait.cpp:24-34
     if (in.stance) {
       const uint32_t sw = *reinterpret_cast<const uint32_t*>(in.stance + 4 * robot);
-      stance_mask = ((sw & 0xFFu) ? 1u : 0u) | ((sw & 0xFF00u) ? 2u : 0u) | ((sw & 0xFF0000u) ? 4u : 0u) | ((sw & 0xFF000000u) ? 8u : 0u);
+      stance = ((sw & 0xFFu) ? 1u : 0u) | ((sw & 0xFF00u) ? 2u : 0u) | ((sw & 0xFF0000u) ? 4u : 0u) | ((sw & 0xFF000000u) ? 8u : 0u);
     }
 #pragma unroll
-    for (int i = 0; i < 4; i++) C.sx[i] = C.sy[i] = C.sz[i] = 0;
+    for (int i = 0; i < FPL; i++) C.sx[i] = C.sy[i] = C.sz[i] = 0;
     if (warm) {
       const uint32_t wv = warm[robot];
-      if (wv & 0x80000000u) decode_states(wv, C);
+      if (wv & 0x80000000u) {
 #pragma unroll
-      for (int i = 0; i < 4; i++)
-        if (!((stance_mask >> i) & 1u)) C.sx[i] = C.sy[i] = C.sz[i] = 0;
+        for (int i = 0; i < FPL; i++) {
+          const uint32_t fb = wv >> (6 * (foot0 + i));
+          const bool st = (stance >> (foot0 + i)) & 1u;
+          C.sx[i] = st ? dec2(fb) : 0;
+          C.sy[i] = st ? dec2(fb >> 2) : 0;
+          C.sz[i] = st ? dec2(fb >> 4) : 0;
+        }
+      }
     }
 #pragma unroll
-    for (int k = 0; k < 12; k++) f[k] = 0.0;
+    for (int k = 0; k < 3 * FPL; k++) f[k] = 0.0;
     status = QC_MAX_ITER;
     iters = 0;
     have_f = false;
-    // non-finite inputs poison b, r or R: report them as QC_NOT_PD instead of iterating on NaNs
-    double fin = 0.0;
-#pragma unroll
-    for (int k = 0; k < 6; k++) fin = __builtin_fma(Wr.b[k], 0.0, fin);
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-      for (int k = 0; k < 3; k++) fin = __builtin_fma(Wr.r[i][k], 0.0, fin);
-#pragma unroll
-    for (int k = 0; k < 9; k++) fin = __builtin_fma(R[k], 0.0, fin);
-    if (!(fin == 0.0)) {  // make every later quantity finite; iterate() then reports NOT_PD through the flag below
+    // non-finite inputs poison b, r or R: report QC_NOT_PD instead of iterating on NaNs
+    const int bad = group_or<G>(!(fin == 0.0) ? 1 : 0);
+    if (bad) {
 #pragma unroll
       for (int k = 0; k < 6; k++) Wr.b[k] = 0.0;
 #pragma unroll
-      for (int i = 0; i < 4; i++) Wr.r[i][0] = Wr.r[i][1] = Wr.r[i][2] = 0.0;
-      stance_mask |= 0x100u;  // bit 8: poisoned input
+      for (int i = 0; i < FPL; i++) Wr.r[i][0] = Wr.r[i][1] = Wr.r[i][2] = 0.0;
+      stance |= 0x100u;
     }
   }
 
@@ -185,48 +192,56 @@ struct Lane {
     double R[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) R[k] = Rp[k];
-    const int st_out = (stance_mask & 0x100u) ? (int)QC_NOT_PD : status;
-    double* o = out.grf_body + 12 * idx;
+    const int st_out = (stance & 0x100u) ? (int)QC_NOT_PD : status;
+    double* o = out.grf_body + 12 * idx + 3 * foot0;
+    uint32_t word = 0;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const bool st = ((stance_mask >> i) & 1u) && st_out == QC_SOLVED;
+    for (int i = 0; i < FPL; i++) {
+      const bool st = ((stance >> (foot0 + i)) & 1u) && st_out == QC_SOLVED;
 #pragma unroll
       for (int r = 0; r < 3; r++) {
         const double v = -(R[r] * f[3 * i] + R[3 + r] * f[3 * i + 1] + R[6 + r] * f[3 * i + 2]);
         o[3 * i + r] = st ? v : 0.0;
       }
+      word |= encode_foot(C.sx[i], C.sy[i], C.sz[i]) << (6 * (foot0 + i));
     }
-    out.status[idx] = st_out;
-    if (out.active_set) out.active_set[idx] = encode_states(C);
-    if (out.iterations) out.iterations[idx] = iters;
+    word = (uint32_t)group_or<G>((int)word) | 0x80000000u;
+    if (foot0 == 0) {
+      out.status[idx] = st_out;
+      if (out.active_set) out.active_set[idx] = word;
+      if (out.iterations) out.iterations[idx] = iters;
+    }
   }
 };
 
 template <class Eqp, int MIN_WAVES_PER_SIMD>
 __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const DevParams* __restrict__ Pg, const long n, const BatchIn in,
-                                                        const uint32_t* __restrict__ warm, const BatchOut out, const long chunk,
-                                                        const int refill_t) {
+                                                                         const uint32_t* __restrict__ warm, const BatchOut out, const long chunk,
+                                                                         const int refill_t) {
+  constexpr int G = Eqp::G;
   extern __shared__ __attribute__((aligned(16))) double qc_lds[];  // dense path: 78 planes x 64 lanes; unused (size 0) otherwise
   long cursor = (long)blockIdx.x * chunk;  // wave-uniform
   const long end = cursor + chunk < n ? cursor + chunk : n;
+  const int member = threadIdx.x & (G - 1);
   Lane<Eqp> L;
   L.idx = -1;
+  L.foot0 = member * (4 / G);
   Eqp eqp(qc_lds + threadIdx.x);
-  bool busy = false;     // lane holds an unfinished robot
-  bool parked = false;   // lane holds a finished robot whose outputs are not stored yet
+  bool busy = false;     // group holds an unfinished robot
+  bool parked = false;   // group holds a finished robot whose outputs are not stored yet
   for (;;) {
     const unsigned long long busy_mask = __builtin_amdgcn_ballot_w64(busy);
-    const int n_free = 64 - __builtin_popcountll(busy_mask);
+    const int n_free = (64 - __builtin_popcountll(busy_mask)) / G;  // free groups
     const long remaining = end - cursor;
     const bool refill = remaining > 0 && (n_free >= refill_t || busy_mask == 0);
     if (refill || busy_mask == 0) {
       if (parked) { L.store(in, out); parked = false; }
     }
     if (refill) {
-      const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(~busy_mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)~busy_mask, 0));
+      const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(~busy_mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)~busy_mask, 0)) / G;
       if (!busy && rank < remaining) {
         CParams& P = *QC_PARAMS_HERE(Pg);
-        L.load(P, in, warm, cursor + rank);
+        L.load(P, in, warm, cursor + rank, member);
         eqp.setup(P, L.Wr);
         busy = true;
       }
@@ -244,15 +259,6 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
   }
 }
 
-template <bool UNIFORM>
-struct EqpDiagW {
-  QC_DEV explicit EqpDiagW(double*) {}
-  QC_DEV void setup(CParams&, const Wrench&) {}
-  QC_DEV bool solve(CParams& P, const Wrench& Wr, const Cube& C, uint32_t stance_mask, double (&f)[12], double (&g)[12]) {
-    return eqp_diagw<UNIFORM>(P, Wr, C, stance_mask, f, g);
-  }
-};
-
 }  // namespace qc
 
 // =============================================================== host / C ABI
@@ -265,12 +271,14 @@ struct qc_handle {
   int wave_slots;       // CUs x 4 SIMDs x resident waves per SIMD
   int refill_t;         // parked lanes that trigger a refill
   long chunk_override;  // development knob (QC_CHUNK)
+  int group_override;   // development knob (QC_GROUP): lanes per robot
   // staging buffers for the host-pointer entry points
   void* stage;
   size_t stage_bytes;
   hipStream_t stream;
 };
 
+#define QC_COMMA(...) __VA_ARGS__
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) {
   g_err = msg;
@@ -398,6 +406,8 @@ int qc_create(const qc_params* p, int device, qc_handle** out) {
   if (const char* e = std::getenv("QC_REFILL_T")) h->refill_t = std::atoi(e);    // development knobs
   if (const char* e = std::getenv("QC_CHUNK")) h->chunk_override = std::atol(e);
   if (const char* e = std::getenv("QC_WAVE_SLOTS")) h->wave_slots = std::atoi(e);
+  h->group_override = 0;
+  if (const char* e = std::getenv("QC_GROUP")) { const int g = std::atoi(e); if (g == 1 || g == 2 || g == 4) h->group_override = g; }
   if (hipSetDevice(device) != hipSuccess || hipMalloc((void**)&h->d_params, sizeof(qc::DevParams)) != hipSuccess ||
       hipMemcpy(h->d_params, &h->dp, sizeof(qc::DevParams), hipMemcpyHostToDevice) != hipSuccess) {
     delete h;
@@ -425,21 +435,38 @@ int qc_control_batch(qc_handle* h, size_t n, const qc_batch_in* in, const uint32
   QC_HIP(hipSetDevice(h->device));
   qc::BatchIn bi{in->Rwb, in->Rwb_d, in->x, in->xdot, in->w, in->x_d, in->xdot_d, in->w_d, in->feet, in->stance};
   qc::BatchOut bo{out->grf_body, out->status, out->active_set, out->iterations};
-  // One wave per 64-thread block.  Small batches: one fill of <= 64 robots per
-  // wave.  Batches larger than the chip holds at once: persistent waves, each
-  // walking a contiguous chunk with lane refill (qc::balance_kernel).
+  // One wave per 64-thread block; a group of G lanes per robot.  The group
+  // width trades latency for throughput: G = 4 (foot per lane) cuts the serial
+  // length of one recalculation (707 instead of 1330 instructions) and is used
+  // while 4 lanes per robot still fit the resident waves; G = 2 costs the same
+  // lane-instructions per robot as G = 1 (the replicated 6x6 solve is paid for
+  // by the halved per-foot work), halves the latency and suffers less from
+  // iteration-count divergence (32 robots per wave), so it serves every larger
+  // batch.  G = 1 remains for the general (non-uniform weights) form.
+  // Batches larger than the chip holds at once run as persistent waves, each
+  // walking a contiguous chunk with lane refill.
+  int G = 1;
+  if (h->diag_w && h->uniform) {
+    const long lanes = (long)h->wave_slots * 64;
+    G = (long)n * 4 <= lanes ? 4 : 2;
+    if (h->group_override) G = h->group_override;
+  }
+  const long rpw = 64 / G;  // robots per wave fill
   const long slots = (long)h->wave_slots;
-  long chunk = 64;
-  if ((long)n > 64 * slots) chunk = (((long)n + slots - 1) / slots + 15) / 16 * 16;
+  long chunk = rpw;
+  if ((long)n > rpw * slots) chunk = (((long)n + slots - 1) / slots + 15) / 16 * 16;
   if (h->chunk_override > 0) chunk = h->chunk_override;
   const unsigned blocks = (unsigned)(((long)n + chunk - 1) / chunk);
-  if (h->diag_w && h->uniform)
-    qc::balance_kernel<qc::EqpDiagW<true>, 2><<<dim3(blocks), dim3(64), 0, (hipStream_t)stream>>>(h->d_params, (long)n, bi, warm, bo, chunk, h->refill_t);
-  else if (h->diag_w)
-    qc::balance_kernel<qc::EqpDiagW<false>, 2><<<dim3(blocks), dim3(64), 0, (hipStream_t)stream>>>(h->d_params, (long)n, bi, warm, bo, chunk, h->refill_t);
-  else
-    qc::balance_kernel<qc::EqpDense, 1><<<dim3(blocks), dim3(64), 78 * 64 * sizeof(double), (hipStream_t)stream>>>(h->d_params, (long)n, bi, warm, bo,
-                                                                                                                   chunk, h->refill_t);
+  const int refill_t = h->refill_t > 0 ? (h->refill_t + G - 1) / G : 1;
+  const hipStream_t st = (hipStream_t)stream;
+#define QC_LAUNCH(EQP, MINW, LDS) \
+  qc::balance_kernel<EQP, MINW><<<dim3(blocks), dim3(64), LDS, st>>>(h->d_params, (long)n, bi, warm, bo, chunk, refill_t)
+  if (!h->diag_w) QC_LAUNCH(qc::EqpDense, 1, 78 * 64 * sizeof(double));
+  else if (!h->uniform) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<false, 1>), 2, 0);
+  else if (G == 4) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<true, 4>), 2, 0);
+  else if (G == 2) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<true, 2>), 2, 0);
+  else QC_LAUNCH(QC_COMMA(qc::EqpDiagW<true, 1>), 2, 0);
+#undef QC_LAUNCH
   QC_HIP(hipGetLastError());
   return QC_OK;
 }

@@ -1,12 +1,17 @@
 // qc_device.hpp - device-side building blocks of the batched balance controller
 // (gfx950 / CDNA4, wave64, FP64 VALU; no MFMA on purpose: the per-robot
-// matrices are 6x6 / 12x12 and every lane owns a different robot).
+// matrices are 6x6 / 12x12 and every lane group owns a different robot).
 //
-// Execution model: ONE LANE = ONE ROBOT (one QP instance), 64 robots per
-// wavefront.  All per-robot state lives in VGPRs with compile-time indexing;
-// batch inputs are read straight from the per-argument arrays of qc_batch_in,
-// so consecutive lanes touch consecutive rows and every fetched cache line is
-// fully consumed by the wave.
+// Execution model: a GROUP of G adjacent lanes (G = 1, 2 or 4) owns one robot
+// (one QP instance); each lane of the group owns 4/G feet.  Per-foot work
+// (face coefficients, contributions to the 6x6 system, forces, ratio test,
+// multipliers) is split across the group, the small dense solve is replicated,
+// and partial sums / minima are combined with DPP quad permutes (no LDS).
+// G = 1 maximises throughput per instruction, G = 4 minimises the serial
+// latency of one working-set recalculation (small batches, stragglers).
+// All per-robot state lives in VGPRs with compile-time indexing; batch inputs
+// are read straight from the per-argument arrays of qc_batch_in, so a wave
+// touches one contiguous span per array and consumes every fetched line.
 //
 // Reference being replaced: BalanceController::control(),
 // quadruped_controller/src/quadruped_controller/balance_controller.cpp:98-330
@@ -19,8 +24,7 @@
 
 namespace qc {
 
-// Uniform (per-handle) constants; passed by value in the kernarg segment so
-// that they are fetched with scalar loads and used as SGPR operands.
+// Uniform (per-handle) constants, uploaded once by qc_create.
 struct DevParams {
   double mu, mass, fzmin, fzmax;
   double Ib[9];
@@ -44,9 +48,9 @@ struct DevParams {
 
 // Device code reads the constants through the CONSTANT address space (scalar
 // loads).  The kernel re-derives the pointer behind an opaque asm before each
-// phase (see QC_PARAMS_HERE) so the ~1.2 KB of constants are fetched where they
-// are used instead of being hoisted out of the persistent loop, which would
-// overflow the 102-SGPR file and spill to VGPR lanes.
+// phase (QC_PARAMS_HERE) so the constants are fetched where they are used
+// instead of being hoisted out of the persistent loop, which would overflow the
+// 102-SGPR file and spill to VGPR lanes.
 typedef const __attribute__((address_space(4))) DevParams CParams;
 #define QC_PARAMS_HERE(ptr)                 \
   ({                                       \
@@ -65,6 +69,48 @@ struct BatchOut {
   uint32_t* active_set;
   int32_t* iterations;
 };
+
+// ------------------------------------------------------------ lane groups
+// DPP quad permutes: data of lane^1 / lane^2 inside each aligned quad.
+QC_DEV int dpp_xor1_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true); }  // quad_perm [1,0,3,2]
+QC_DEV int dpp_xor2_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true); }  // quad_perm [2,3,0,1]
+QC_DEV double dpp_xor1(double v) {
+  const long long b = __double_as_longlong(v);
+  const unsigned lo = (unsigned)dpp_xor1_i((int)(unsigned)b), hi = (unsigned)dpp_xor1_i((int)(unsigned)(b >> 32));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+QC_DEV double dpp_xor2(double v) {
+  const long long b = __double_as_longlong(v);
+  const unsigned lo = (unsigned)dpp_xor2_i((int)(unsigned)b), hi = (unsigned)dpp_xor2_i((int)(unsigned)(b >> 32));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// All-reduce over the G lanes of a group.  x op y is commutative, so every
+// lane of the group ends up with the bit-identical result: decisions taken
+// from reduced values are uniform inside the group.
+template <int G>
+QC_DEV double group_sum(double v) {
+  if (G >= 2) v += dpp_xor1(v);
+  if (G >= 4) v += dpp_xor2(v);
+  return v;
+}
+template <int G>
+QC_DEV double group_min(double v) {
+  if (G >= 2) v = fmin(v, dpp_xor1(v));
+  if (G >= 4) v = fmin(v, dpp_xor2(v));
+  return v;
+}
+template <int G>
+QC_DEV double group_max(double v) {
+  if (G >= 2) v = fmax(v, dpp_xor1(v));
+  if (G >= 4) v = fmax(v, dpp_xor2(v));
+  return v;
+}
+template <int G>
+QC_DEV int group_or(int v) {
+  if (G >= 2) v |= dpp_xor1_i(v);
+  if (G >= 4) v |= dpp_xor2_i(v);
+  return v;
+}
 
 // ---------------------------------------------------------------- small math
 QC_DEV double rsqrt_nr(double d) {
@@ -126,9 +172,11 @@ QC_DEV void angle_axis_total(const double (&m)[9], double (&out)[3]) {
 }
 
 // Per-robot quantities every formulation needs: r_i = Rwb p_i (BC.cpp:244-248)
-// and the wrench target b (BC.cpp:126-139, 264-269).
+// for the FPL feet this lane owns, and the wrench target b (BC.cpp:126-139,
+// 264-269; replicated in every lane of the group).
+template <int FPL>
 struct Wrench {
-  double r[4][3];
+  double r[FPL][3];
   double b[6];
 };
 
@@ -143,8 +191,10 @@ QC_DEV void load9(const double* __restrict__ p, long idx, double (&v)[9]) {
 }
 
 // K0 + K2 + K3 of SURVEY.md 2.2: gather, PD wrench law, SRB dynamics rhs.
-QC_DEV void build_wrench(CParams& P, const BatchIn& in, long idx, double (&R)[9], Wrench& W) {
-  double Rd[9], x[3], xd[3], xdot[3], xdotd[3], w[3], wd[3];
+// `foot0` = first foot owned by this lane.  Returns 0.0 iff every input was finite.
+template <int FPL>
+QC_DEV double build_wrench(CParams& P, const BatchIn& in, long idx, int foot0, Wrench<FPL>& W) {
+  double R[9], Rd[9], x[3], xd[3], xdot[3], xdotd[3], w[3], wd[3];
   load9(in.Rwb, idx, R);
   load9(in.Rwb_d, idx, Rd);
   load3(in.x, idx, x);
@@ -153,9 +203,9 @@ QC_DEV void build_wrench(CParams& P, const BatchIn& in, long idx, double (&R)[9]
   load3(in.xdot_d, idx, xdotd);
   load3(in.w, idx, w);
   load3(in.w_d, idx, wd);
-  const double* fp = in.feet + 12 * idx;
+  const double* fp = in.feet + 12 * idx + 3 * foot0;
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
+  for (int i = 0; i < FPL; i++) {
     double p0 = fp[3 * i], p1 = fp[3 * i + 1], p2 = fp[3 * i + 2];
 #pragma unroll
     for (int k = 0; k < 3; k++) W.r[i][k] = R[3 * k] * p0 + R[3 * k + 1] * p1 + R[3 * k + 2] * p2;  // BC.cpp:244-248
@@ -204,6 +254,17 @@ QC_DEV void build_wrench(CParams& P, const BatchIn& in, long idx, double (&R)[9]
   W.b[3] = Ia[0] + (wd[1] * Iw[2] - wd[2] * Iw[1]);
   W.b[4] = Ia[1] + (wd[2] * Iw[0] - wd[0] * Iw[2]);
   W.b[5] = Ia[2] + (wd[0] * Iw[1] - wd[1] * Iw[0]);
+  // finiteness probe: any NaN/Inf among the inputs that reach b, r or R makes it non-zero/NaN
+  double fin = 0.0;
+#pragma unroll
+  for (int k = 0; k < 6; k++) fin = __builtin_fma(W.b[k], 0.0, fin);
+#pragma unroll
+  for (int i = 0; i < FPL; i++)
+#pragma unroll
+    for (int k = 0; k < 3; k++) fin = __builtin_fma(W.r[i][k], 0.0, fin);
+#pragma unroll
+  for (int k = 0; k < 9; k++) fin = __builtin_fma(R[k], 0.0, fin);
+  return fin;
 }
 
 // ------------------------------------------------------------ active-set state
@@ -212,29 +273,14 @@ QC_DEV void build_wrench(CParams& P, const BatchIn& in, long idx, double (&R)[9]
 // combinatorially a cube: axis X in {fx=-mu fz, free, fx=+mu fz}, same for Y,
 // axis Z in {fz=fzmin, free, fz=fzmax}.  State = (sx,sy,sz) in {-1,0,+1}^3.
 // Swing feet (BC.cpp:312-316: all five rows pinned to 0) are eliminated: f_i=0.
+template <int FPL>
 struct Cube {
-  int sx[4], sy[4], sz[4];
+  int sx[FPL], sy[FPL], sz[FPL];
 };
 
-QC_DEV uint32_t encode_states(const Cube& c) {
-  uint32_t wv = 0;
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    uint32_t f = (uint32_t)(c.sx[i] & 3) | ((uint32_t)(c.sy[i] & 3) << 2) | ((uint32_t)(c.sz[i] & 3) << 4);  // -1 -> 3
-    wv |= f << (6 * i);
-  }
-  return wv | 0x80000000u;  // bit 31: "valid warm word"
-}
+// 6 bits per foot in the warm-start / active_set word; bit 31 = valid.
+QC_DEV uint32_t encode_foot(int sx, int sy, int sz) { return (uint32_t)(sx & 3) | ((uint32_t)(sy & 3) << 2) | ((uint32_t)(sz & 3) << 4); }  // -1 -> 3
 QC_DEV int dec2(uint32_t v) { return (v & 3u) == 3u ? -1 : ((v & 3u) == 1u ? 1 : 0); }
-QC_DEV void decode_states(uint32_t wv, Cube& c) {
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    uint32_t f = wv >> (6 * i);
-    c.sx[i] = dec2(f);
-    c.sy[i] = dec2(f >> 2);
-    c.sz[i] = dec2(f >> 4);
-  }
-}
 
 // Componentwise clamp of one foot into its frustum (branch-free); returns the
 // faces it hit.  lo/hi are the foot's own fz bounds (0,0 for a swing foot).
@@ -276,10 +322,6 @@ QC_DEV double step_cand(bool free_face, double slack, double nd, int code) {
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
-// per-foot fz bounds from the stance bit: a swing foot is pinned to f = 0
-QC_DEV double foot_lo(CParams& P, uint32_t stance_mask, int i) { return ((stance_mask >> i) & 1u) ? P.fzmin : 0.0; }
-QC_DEV double foot_hi(CParams& P, uint32_t stance_mask, int i) { return ((stance_mask >> i) & 1u) ? P.fzmax : 0.0; }
-
 // -------------------------------------------------------------- EQP, diagonal W
 // Equality-constrained subproblem on the current face, 6-dimensional form.
 // With f = T y + p (T,p from the cube states), diagonal W and u = A f - b:
@@ -288,17 +330,17 @@ QC_DEV double foot_hi(CParams& P, uint32_t stance_mask, int i) { return ((stance
 // 6x6 Cholesky per working-set recalculation; the Hessian Q = 2(A^T S A + W)
 // of BC.cpp:152 is never formed.  The gradient needed for the multipliers is
 // g = Q f + c = 2 (A^T v + W f).
+
 // Face coefficients of one foot for the current cube state.
 struct FootCoef {
   double mx, my, fzfix, ix, iy, iz;
 };
 // UNIFORM = (S diagonal, W = w*I): a handful of scalar constants instead of
-// ~60, so they all stay in SGPRs (the general form overflows the SGPR file).
+// ~60, so they all stay in SGPRs.  The per-foot constant tables of the general
+// form are indexed with the compile-time foot number, hence G = 1 only there.
 template <bool UNIFORM>
-QC_DEV FootCoef foot_coef(CParams& P, const Cube& C, uint32_t stance_mask, int i) {
+QC_DEV FootCoef foot_coef(CParams& P, int sx, int sy, int sz, bool st, int foot) {
   FootCoef k;
-  const bool st = (stance_mask >> i) & 1u;
-  const int sx = C.sx[i], sy = C.sy[i], sz = C.sz[i];
   k.mx = P.mu * (double)sx;
   k.my = P.mu * (double)sy;
   k.fzfix = st ? (sz > 0 ? P.fzmax : (sz < 0 ? P.fzmin : 0.0)) : 0.0;
@@ -309,32 +351,35 @@ QC_DEV FootCoef foot_coef(CParams& P, const Cube& C, uint32_t stance_mask, int i
     const double b0 = sy != 0 ? P.inv_bz_u[1] : P.inv_bz_u[0];
     k.iz = (st && sz == 0) ? (sx != 0 ? b1 : b0) : 0.0;
   } else {
-    k.ix = (st && sx == 0) ? P.inv_wx[i] : 0.0;
-    k.iy = (st && sy == 0) ? P.inv_wy[i] : 0.0;
-    const double b0 = sy != 0 ? P.inv_bz[4 * i + 1] : P.inv_bz[4 * i];
-    const double b1 = sy != 0 ? P.inv_bz[4 * i + 3] : P.inv_bz[4 * i + 2];
+    k.ix = (st && sx == 0) ? P.inv_wx[foot] : 0.0;
+    k.iy = (st && sy == 0) ? P.inv_wy[foot] : 0.0;
+    const double b0 = sy != 0 ? P.inv_bz[4 * foot + 1] : P.inv_bz[4 * foot];
+    const double b1 = sy != 0 ? P.inv_bz[4 * foot + 3] : P.inv_bz[4 * foot + 2];
     k.iz = (st && sz == 0) ? (sx != 0 ? b1 : b0) : 0.0;
   }
   return k;
 }
 
-template <bool UNIFORM>
-QC_DEV bool eqp_diagw(CParams& P, const Wrench& Wr, const Cube& C, uint32_t stance_mask, double (&f)[12], double (&g)[12]) {
+// `stance` = 4-bit mask of the robot, `foot0` = first foot of this lane.
+template <bool UNIFORM, int G>
+QC_DEV bool eqp_diagw(CParams& P, const Wrench<4 / G>& Wr, const Cube<4 / G>& C, uint32_t stance, int foot0, double (&f)[12 / G],
+                      double (&g)[12 / G]) {
+  constexpr int FPL = 4 / G;
+  static_assert(UNIFORM || G == 1, "per-foot weight tables need compile-time foot numbers");
   double M[21];
   // packed lower triangle index r*(r+1)/2 + c
 #define MI(r, c) ((r) * ((r) + 1) / 2 + (c))
 #pragma unroll
-  for (int r = 0; r < 6; r++)
-#pragma unroll
-    for (int c = 0; c <= r; c++) M[MI(r, c)] = UNIFORM ? (r == c ? P.Vd[r] : 0.0) : P.V[6 * r + c];
+  for (int k = 0; k < 21; k++) M[k] = 0.0;
   double rhs[6];
 #pragma unroll
-  for (int k = 0; k < 6; k++) rhs[k] = -Wr.b[k];
+  for (int k = 0; k < 6; k++) rhs[k] = 0.0;
 
-  // pass 1: accumulate M = S^-1 + sum_i A~_i B_i^-1 A~_i^T and rhs = -(b - A p)
+  // pass 1: this lane's part of sum_i A~_i B_i^-1 A~_i^T and of A p
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const FootCoef k = foot_coef<UNIFORM>(P, C, stance_mask, i);
+  for (int i = 0; i < FPL; i++) {
+    const bool st = (stance >> (foot0 + i)) & 1u;
+    const FootCoef k = foot_coef<UNIFORM>(P, C.sx[i], C.sy[i], C.sz[i], st, G == 1 ? i : 0);
     const double rx = Wr.r[i][0], ry = Wr.r[i][1], rz = Wr.r[i][2];
     double q[6];
     q[0] = k.mx; q[1] = k.my; q[2] = 1.0;
@@ -371,6 +416,16 @@ QC_DEV bool eqp_diagw(CParams& P, const Wrench& Wr, const Cube& C, uint32_t stan
       for (int r = c; r < 6; r++) M[MI(r, c)] = __builtin_fma(q[r], tq, M[MI(r, c)]);
     }
   }
+  // combine the group's partial sums, then add S^-1 and -b
+#pragma unroll
+  for (int r = 0; r < 6; r++) {
+#pragma unroll
+    for (int c = 0; c <= r; c++) {
+      const double s = group_sum<G>(M[MI(r, c)]);
+      M[MI(r, c)] = s + (UNIFORM ? (r == c ? P.Vd[r] : 0.0) : P.V[6 * r + c]);
+    }
+    rhs[r] = group_sum<G>(rhs[r]) - Wr.b[r];
+  }
   // Cholesky M = L L^T (in place; diagonal holds 1/L_kk)
   bool ok = true;
 #pragma unroll
@@ -406,11 +461,13 @@ QC_DEV bool eqp_diagw(CParams& P, const Wrench& Wr, const Cube& C, uint32_t stan
     v[k] = t * M[MI(k, k)];
   }
 #undef MI
-  // pass 2: forces and gradient (face coefficients recomputed, not kept live
-  // across the factorisation: registers matter more than ~12 selects per foot)
+  // pass 2: forces and gradient of this lane's feet (face coefficients are
+  // recomputed, not kept live across the factorisation: registers matter
+  // more than ~12 selects per foot)
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const FootCoef k = foot_coef<UNIFORM>(P, C, stance_mask, i);
+  for (int i = 0; i < FPL; i++) {
+    const bool st = (stance >> (foot0 + i)) & 1u;
+    const FootCoef k = foot_coef<UNIFORM>(P, C.sx[i], C.sy[i], C.sz[i], st, G == 1 ? i : 0);
     const double rx = Wr.r[i][0], ry = Wr.r[i][1], rz = Wr.r[i][2];
     const double ax = v[0] + v[4] * rz - v[5] * ry;  // (A_i^T v)_x
     const double ay = v[1] + v[5] * rx - v[3] * rz;
@@ -420,12 +477,23 @@ QC_DEV bool eqp_diagw(CParams& P, const Wrench& Wr, const Cube& C, uint32_t stan
     const double fx = __builtin_fma(k.mx, fz, -k.ix * ax);
     const double fy = __builtin_fma(k.my, fz, -k.iy * ay);
     f[3 * i] = fx; f[3 * i + 1] = fy; f[3 * i + 2] = fz;
-    g[3 * i] = 2.0 * __builtin_fma(UNIFORM ? P.w_u : P.w[3 * i], fx, ax);
-    g[3 * i + 1] = 2.0 * __builtin_fma(UNIFORM ? P.w_u : P.w[3 * i + 1], fy, ay);
-    g[3 * i + 2] = 2.0 * __builtin_fma(UNIFORM ? P.w_u : P.w[3 * i + 2], fz, az);
+    g[3 * i] = 2.0 * __builtin_fma(UNIFORM ? P.w_u : P.w[3 * (G == 1 ? i : 0)], fx, ax);
+    g[3 * i + 1] = 2.0 * __builtin_fma(UNIFORM ? P.w_u : P.w[3 * (G == 1 ? i : 0) + 1], fy, ay);
+    g[3 * i + 2] = 2.0 * __builtin_fma(UNIFORM ? P.w_u : P.w[3 * (G == 1 ? i : 0) + 2], fz, az);
   }
   return ok;
 }
+
+template <bool UNIFORM, int GROUP>
+struct EqpDiagW {
+  static constexpr int G = GROUP;
+  QC_DEV explicit EqpDiagW(double*) {}
+  QC_DEV void setup(CParams&, const Wrench<4 / GROUP>&) {}
+  QC_DEV bool solve(CParams& P, const Wrench<4 / GROUP>& Wr, const Cube<4 / GROUP>& C, uint32_t stance, int foot0, double (&f)[12 / GROUP],
+                    double (&g)[12 / GROUP]) {
+    return eqp_diagw<UNIFORM, GROUP>(P, Wr, C, stance, foot0, f, g);
+  }
+};
 
 // ------------------------------------------------------------ EQP, general W
 // Dense formulation for a general SPD W (the API allows any 12x12 SPD W,
@@ -437,9 +505,11 @@ QC_DEV bool eqp_diagw(CParams& P, const Wrench& Wr, const Cube& C, uint32_t stan
 // recalculation forms the masked reduced Hessian H = T^T Q T + (I - D) in
 // registers (fixed 12x12 shape, identity rows on fixed slots, so indexing stays
 // compile-time), factorises it with an unrolled Cholesky and back-substitutes.
+// One lane per robot (G = 1).
 #define QC_SYM(r, c) ((r) >= (c) ? ((r) * ((r) + 1) / 2 + (c)) : ((c) * ((c) + 1) / 2 + (r)))
 
 struct EqpDense {
+  static constexpr int G = 1;
   double* Qs;    // LDS base of this lane: element k at Qs[k * 64]
   double c[12];  // c = -2 A^T S b (BC.cpp:153)
 
@@ -448,7 +518,7 @@ struct EqpDense {
   QC_DEV explicit EqpDense(double* lds_lane) : Qs(lds_lane) {}
 
   // assemble Q (into LDS) and c for the robot this lane just fetched
-  QC_DEV void setup(CParams& P, const Wrench& Wr) {
+  QC_DEV void setup(CParams& P, const Wrench<4>& Wr) {
     double Sb[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) {
@@ -492,11 +562,11 @@ struct EqpDense {
     }
   }
 
-  QC_DEV bool solve(CParams& P, const Wrench&, const Cube& C, uint32_t stance_mask, double (&f)[12], double (&g)[12]) {
+  QC_DEV bool solve(CParams& P, const Wrench<4>&, const Cube<4>& C, uint32_t stance, int, double (&f)[12], double (&g)[12]) {
     double ax[4], ay[4], az[4], cx[4], cy[4], mx[4], my[4], fzfix[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      const bool st = (stance_mask >> i) & 1u;
+      const bool st = (stance >> i) & 1u;
       const int sx = C.sx[i], sy = C.sy[i], sz = C.sz[i];
       ax[i] = (st && sx == 0) ? 1.0 : 0.0;
       ay[i] = (st && sy == 0) ? 1.0 : 0.0;
