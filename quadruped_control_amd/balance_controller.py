@@ -149,6 +149,40 @@ class BalanceController:
             raise RuntimeError(f"qc_control_batch failed ({rc}): {_lib.last_error()}")
         return out
 
+    def plan_batch(self, batch, warm=None, out=None, want_active_set=False, want_iterations=False, stream=None):
+        """Validate and marshal the arguments of control_batch() once and return
+        (launch, out): `launch()` is a single C call (qc_control_batch) that can be
+        issued every tick without Python-side marshalling, e.g. in a simulation or
+        benchmark loop where the tensors are updated in place."""
+        import torch
+
+        n = batch["x"].shape[0]
+        dev = torch.device("cuda", self.device)
+        first = self.control_batch(batch, warm=warm, out=out, want_active_set=want_active_set,
+                                   want_iterations=want_iterations, stream=stream)  # validates + allocates
+        bi = _lib.QcBatchIn()
+        for name, _ in _IN_FIELDS:
+            setattr(bi, name, batch[name].data_ptr())
+        if batch.get("stance") is not None:
+            bi.stance = batch["stance"].data_ptr()
+        bo = _lib.QcBatchOut()
+        bo.grf_body = first["grf_body"].data_ptr()
+        bo.status = first["status"].data_ptr()
+        bo.active_set = first["active_set"].data_ptr() if "active_set" in first else None
+        bo.iterations = first["iterations"].data_ptr() if "iterations" in first else None
+        warm_ptr = warm.data_ptr() if warm is not None else None
+        s = stream if stream is not None else torch.cuda.current_stream(dev)
+        fn, h, sp = self._lib.qc_control_batch, self._h, C.c_void_p(s.cuda_stream)
+        bi_ref, bo_ref = C.byref(bi), C.byref(bo)
+        keep = (batch, warm, first, bi, bo)
+
+        def launch(_keep=keep):
+            rc = fn(h, n, bi_ref, warm_ptr, bo_ref, sp)
+            if rc != _lib.QC_OK:
+                raise RuntimeError(f"qc_control_batch failed ({rc}): {_lib.last_error()}")
+
+        return launch, first
+
     def control_batch_host(self, batch, warm=None, want_active_set=False, want_iterations=False):
         """n robots, numpy (host) arrays in and out; PCIe-inclusive convenience path."""
         n = batch["x"].shape[0]
