@@ -82,10 +82,14 @@ def time_steps(ctl, dev_batch, warm, out, steps, warmup, dist=None):
     return wall, ev0.elapsed_time(ev1) * 1e-3
 
 
-def run_config(ctl, q, cfg, n, start, steps, warmup, dist=None, device=0):
+def run_config(ctl, q, cfg, n, start, steps, warmup, dist=None, device=0, fused=False):
     import torch
 
     batch, prev = make_batch(cfg, n, start)
+    if fused:  # SURVEY 8f rows 1+2: joint angles in (device FK), joint torques out (J^T f, clamped)
+        from quadruped_control_amd import workloads as W
+
+        batch = W.with_joint_angles(batch, start=start)
     dev_batch = q.to_device(batch, device)
     warm = None
     if prev is not None:  # config 4: tick 0 (cold) produces the warm-start words for tick 1
@@ -96,6 +100,8 @@ def run_config(ctl, q, cfg, n, start, steps, warmup, dist=None, device=0):
            "status": torch.empty((n,), dtype=torch.int32, device=f"cuda:{device}")}
     if warm is not None:
         out["active_set"] = torch.empty((n,), dtype=torch.int32, device=f"cuda:{device}")
+    if fused:
+        out["joint_tau"] = torch.empty((n, 12), dtype=torch.float64, device=f"cuda:{device}")
     wall, evs = time_steps(ctl, dev_batch, warm, out, steps, warmup, dist)
     solved = int((out["status"] == 0).sum().item())
     return dict(wall=wall, event_s=evs, solved=solved, n=n, batch=batch, warm=warm is not None)
@@ -245,6 +251,10 @@ def main():
                 other[f"config{c}"] = {"robots": CONFIG_N[c], "QPs_per_s": CONFIG_N[c] * k / r["wall"],
                                        "solved_fraction": r["solved"] / CONFIG_N[c],
                                        "hbm_GBs": (BYTES_PER_ROBOT_WARM if r["warm"] else BYTES_PER_ROBOT_COLD) * CONFIG_N[c] * k / r["event_s"] / 1e9}
+            r = run_config(ctl, q, 2, CONFIG_N[2], 0, max(5, min(args.steps, 50)), 3, None, device, fused=True)
+            other["config2_fused_tick"] = {"robots": CONFIG_N[2], "QPs_per_s": CONFIG_N[2] * max(5, min(args.steps, 50)) / r["wall"],
+                                           "solved_fraction": r["solved"] / CONFIG_N[2],
+                                           "what": "joint_q -> forward kinematics -> control() -> clamp(J^T f) -> joint_tau in one launch (584 B/robot)"}
             line["other_configs"] = other
         print(json.dumps(line), flush=True)
 

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define QC_ABI_VERSION 1
+#define QC_ABI_VERSION 2
 
 /* Replaces the constructor arguments of BalanceController
  * (balance_controller.hpp:85-88; defaults in commander_node.cpp:289-334 and
@@ -60,6 +60,11 @@ typedef struct qc_batch_in {
   const double* w_d;     /* [n][3]  desired COM angular velocity             */
   const double* feet;    /* [n][4][3] foot positions, body frame (FootholdMap, types.hpp:108) */
   const uint8_t* stance; /* [n][4]  LegState per leg: 1 stance, 0 swing (GaitMap, types.hpp:91-100) */
+  /* ABI v2, optional (NULL = unused).  Joint angles [n][4][3] (RL,FL,RR,FR x hip,thigh,calf; JointStatesMap,
+   * types.hpp:127).  When given, the foot positions are computed on the device by the reference's forward
+   * kinematics (kinematics.cpp:81-103, what commander_node.cpp:383-384 does before control()) and `feet`
+   * is ignored (may be NULL). */
+  const double* joint_q;
 } qc_batch_in;
 
 /* Replaces the returned ForceMap (types.hpp:119; balance_controller.cpp:218-232). */
@@ -69,7 +74,21 @@ typedef struct qc_batch_out {
   int32_t* status;      /* [n] qc_status; != 0 is the reference's "empty ForceMap" (balance_controller.cpp:182-216) */
   uint32_t* active_set; /* [n] optional (may be NULL): optimal working set, feed back as `warm` next tick */
   int32_t* iterations;  /* [n] optional (may be NULL): working-set recalculations used */
+  /* ABI v2, optional (NULL = unused; needs qc_batch_in.joint_q).  Stance-leg joint torques [n][4][3]:
+   * tau = J(q_leg)^T f_body (QuadrupedKinematics::jacobianTransposeControl, kinematics.cpp:219-231 with
+   * legJacobian :162-188), clamped to [tau_min, tau_max] as commander_node.cpp:523-526; swing legs (whose
+   * torques the reference takes from its joint PD, out of scope) and failed instances get 0. */
+  double* joint_tau;
 } qc_batch_out;
+
+/* Kinematic constants of QuadrupedKinematics::QuadrupedKinematics() (kinematics.cpp:20-47) and the torque
+ * limits of commander_node.cpp:324-325.  qc_create installs the reference's values. */
+typedef struct qc_kinematics {
+  double hip[12];   /* [leg][xyz] translation base -> hip   (trans_rl/fl/rr/fr)            */
+  double links[12]; /* [leg][l1,l2,l3] signed link lengths  (left_links / right_links)     */
+  double tau_min;   /* balance_control/torque_min (-20)                                     */
+  double tau_max;   /* balance_control/torque_max (+20)                                     */
+} qc_kinematics;
 
 typedef enum qc_status {
   QC_SOLVED = 0,
@@ -111,6 +130,10 @@ int qc_control(qc_handle* h, const double* Rwb, const double* Rwb_d, const doubl
                const double* xdot, const double* w, const double* x_d, const double* xdot_d,
                const double* w_d, const double* feet, const uint8_t* stance, double* grf_body,
                int32_t* status);
+
+/* Kinematic model used by the joint_q / joint_tau extension; NULL restores the reference's constants. */
+void qc_default_kinematics(qc_kinematics* out);
+int qc_set_kinematics(qc_handle* h, const qc_kinematics* kin);
 
 /* Thread-local message of the last failing call (ROS_ERROR replacement,
  * balance_controller.cpp:157,184,199,214). */

@@ -392,3 +392,72 @@ void oracle_control_batch(const oracle_params* P, long n, const double* Rwb, con
     if (iters) iters[i] = it;
   }
 }
+
+/* ------------------------------------------------ kinematics either side of control() */
+void oracle_default_kinematics(oracle_kinematics* k) {
+  /* kinematics.cpp:22-42 */
+  const double xbh = 0.196, ybh = 0.050, zbh = 0.0;
+  const double l1 = 0.077, l2 = 0.211, l3 = 0.230;
+  const double trans[4][3] = {{-xbh, ybh, zbh}, {xbh, ybh, zbh}, {-xbh, -ybh, zbh}, {xbh, -ybh, zbh}}; /* RL FL RR FR */
+  const double left_links[3] = {l1, -l2, -l3}, right_links[3] = {-l1, -l2, -l3};
+  for (int leg = 0; leg < 4; leg++)
+    for (int c = 0; c < 3; c++) {
+      k->hip[3 * leg + c] = trans[leg][c];
+      k->links[3 * leg + c] = (leg < 2) ? left_links[c] : right_links[c];
+    }
+  k->tau_min = -20.0; /* commander_node.cpp:324 */
+  k->tau_max = 20.0;  /* commander_node.cpp:325 */
+}
+
+void oracle_leg_fk(const oracle_kinematics* k, int leg, const double* q, double* p) {
+  /* kinematics.cpp:81-103 */
+  const double l1 = k->links[3 * leg], l2 = k->links[3 * leg + 1], l3 = k->links[3 * leg + 2];
+  const double t1 = q[0], t2 = q[1], t3 = q[2];
+  p[0] = l2 * sin(t2) + l3 * sin(t2 + t3) + k->hip[3 * leg];
+  p[1] = l1 * cos(t1) - l2 * sin(t1) * cos(t2) - l3 * sin(t1) * cos(t2 + t3) + k->hip[3 * leg + 1];
+  p[2] = l1 * sin(t1) + l2 * cos(t1) * cos(t2) + l3 * cos(t1) * cos(t2 + t3) + k->hip[3 * leg + 2];
+}
+
+void oracle_leg_jacobian(const oracle_kinematics* k, int leg, const double* q, double* jac) {
+  /* kinematics.cpp:162-188 */
+  const double l1 = k->links[3 * leg], l2 = k->links[3 * leg + 1], l3 = k->links[3 * leg + 2];
+  const double t1 = q[0], t2 = q[1], t3 = q[2];
+  jac[0] = 0.0;
+  jac[1] = l2 * cos(t2) + l3 * cos(t2 + t3);
+  jac[2] = l3 * cos(t2 + t3);
+  jac[3] = -l1 * sin(t1) - l2 * cos(t1) * cos(t2) - l3 * cos(t1) * cos(t2 + t3);
+  jac[4] = (l2 * sin(t2) + l3 * sin(t2 + t3)) * sin(t1);
+  jac[5] = l3 * sin(t1) * sin(t2 + t3);
+  jac[6] = l1 * cos(t1) - l2 * sin(t1) * cos(t2) - l3 * sin(t1) * cos(t2 + t3);
+  jac[7] = -(l2 * sin(t2) + l3 * sin(t2 + t3)) * cos(t1);
+  jac[8] = -l3 * sin(t2 + t3) * cos(t1);
+}
+
+void oracle_tick_batch(const oracle_params* P, const oracle_kinematics* K, long n, const double* Rwb,
+                       const double* Rwb_d, const double* x, const double* xdot, const double* w,
+                       const double* x_d, const double* xdot_d, const double* w_d, const double* joint_q,
+                       const unsigned char* stance, double* feet_out, double* grf_body, double* joint_tau,
+                       int* status, int threads) {
+  if (threads < 1) threads = 1;
+#pragma omp parallel for num_threads(threads) schedule(static)
+  for (long i = 0; i < n; i++) {
+    double feet[12];
+    for (int leg = 0; leg < 4; leg++) oracle_leg_fk(K, leg, joint_q + 12 * i + 3 * leg, feet + 3 * leg); /* commander_node.cpp:383-384 */
+    if (feet_out) memcpy(feet_out + 12 * i, feet, sizeof(feet));
+    int it = 0;
+    int st = oracle_control(P, Rwb + 9 * i, Rwb_d + 9 * i, x + 3 * i, xdot + 3 * i, w + 3 * i, x_d + 3 * i,
+                            xdot_d + 3 * i, w_d + 3 * i, feet, stance + 4 * i, grf_body + 12 * i, 0, &it);
+    if (status) status[i] = st;
+    for (int leg = 0; leg < 4; leg++) {
+      double J[9];
+      oracle_leg_jacobian(K, leg, joint_q + 12 * i + 3 * leg, J);
+      const double* f = grf_body + 12 * i + 3 * leg;
+      for (int c = 0; c < 3; c++) {
+        double t = J[c] * f[0] + J[3 + c] * f[1] + J[6 + c] * f[2]; /* tau = J^T f, kinematics.cpp:226 */
+        if (t < K->tau_min) t = K->tau_min;                          /* arma::clamp, commander_node.cpp:526 */
+        if (t > K->tau_max) t = K->tau_max;
+        joint_tau[12 * i + 3 * leg + c] = (st == ORACLE_OK && stance[4 * i + leg]) ? t : 0.0;
+      }
+    }
+  }
+}

@@ -70,6 +70,28 @@ void oracle_control_batch(const oracle_params* P, long n, const double* Rwb, con
                           const unsigned char* stance, double* grf_body, int* status, int* iters,
                           int threads);
 
+/* ---- "next" rows of the scope table: the steps either side of control() ----
+ * Kinematic model of QuadrupedKinematics::QuadrupedKinematics(), src/quadruped_controller/kinematics.cpp:20-47
+ * (leg order RL, FL, RR, FR). */
+typedef struct oracle_kinematics {
+  double hip[12];   /* base -> hip translation per leg */
+  double links[12]; /* signed (l1, l2, l3) per leg     */
+  double tau_min, tau_max; /* commander_node.cpp:324-325 */
+} oracle_kinematics;
+void oracle_default_kinematics(oracle_kinematics* k);
+/* forwardKinematics(leg, q), kinematics.cpp:81-103 */
+void oracle_leg_fk(const oracle_kinematics* k, int leg, const double* q3, double* p3);
+/* legJacobian(leg, q), kinematics.cpp:162-188 (row-major 3x3) */
+void oracle_leg_jacobian(const oracle_kinematics* k, int leg, const double* q3, double* J9);
+/* One tick as commander_node.cpp:383-384 + 507-526 chains it:
+ * feet = FK(q); forces = control(...); tau = clamp(J^T f_body) for stance legs (kinematics.cpp:219-231),
+ * 0 for swing legs and failed instances. */
+void oracle_tick_batch(const oracle_params* P, const oracle_kinematics* K, long n, const double* Rwb,
+                       const double* Rwb_d, const double* x, const double* xdot, const double* w,
+                       const double* x_d, const double* xdot_d, const double* w_d, const double* joint_q,
+                       const unsigned char* stance, double* feet_out, double* grf_body, double* joint_tau,
+                       int* status, int threads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,6 +19,10 @@ class OracleParams(C.Structure):
                 ("kp_w", C.c_double * 3), ("kd_w", C.c_double * 3), ("max_iter", C.c_int)]
 
 
+class OracleKinematics(C.Structure):
+    _fields_ = [("hip", C.c_double * 12), ("links", C.c_double * 12), ("tau_min", C.c_double), ("tau_max", C.c_double)]
+
+
 def build(force=False):
     src = os.path.join(_HERE, "balance_oracle.c")
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
@@ -98,3 +102,37 @@ def control_batch(P, batch, threads=1, max_iter=200):
                                _dp(grf), status.ctypes.data_as(C.POINTER(C.c_int)),
                                iters.ctypes.data_as(C.POINTER(C.c_int)), C.c_int(threads))
     return grf, status, iters
+
+
+def default_kinematics():
+    k = OracleKinematics()
+    lib().oracle_default_kinematics(C.byref(k))
+    return k
+
+
+def leg_fk(leg, q, kin=None):
+    kin = kin or default_kinematics()
+    q = np.ascontiguousarray(q, np.float64); p = np.zeros(3)
+    lib().oracle_leg_fk(C.byref(kin), C.c_int(leg), _dp(q), _dp(p))
+    return p
+
+
+def leg_jacobian(leg, q, kin=None):
+    kin = kin or default_kinematics()
+    q = np.ascontiguousarray(q, np.float64); J = np.zeros((3, 3))
+    lib().oracle_leg_jacobian(C.byref(kin), C.c_int(leg), _dp(q), _dp(J))
+    return J
+
+
+def tick_batch(P, batch, kin=None, threads=1, max_iter=200):
+    """FK -> control() -> J^T f -> clamp for n robots; batch holds 'joint_q' [n,12]."""
+    kin = kin or default_kinematics()
+    p = make_params(P, max_iter)
+    n = batch["x"].shape[0]
+    names = ("Rwb", "Rwb_d", "x", "xdot", "w", "x_d", "xdot_d", "w_d", "joint_q")
+    a = [np.ascontiguousarray(batch[k], np.float64) for k in names]
+    st = np.ascontiguousarray(batch["stance"], np.uint8)
+    feet = np.zeros((n, 12)); grf = np.zeros((n, 12)); tau = np.zeros((n, 12)); status = np.zeros(n, np.int32)
+    lib().oracle_tick_batch(C.byref(p), C.byref(kin), C.c_long(n), *[_dp(v) for v in a], st.ctypes.data_as(C.POINTER(C.c_ubyte)),
+                            _dp(feet), _dp(grf), _dp(tau), status.ctypes.data_as(C.POINTER(C.c_int)), C.c_int(threads))
+    return dict(feet=feet, grf_body=grf, joint_tau=tau, status=status)

@@ -26,15 +26,19 @@ class QcParams(C.Structure):
 
 class QcBatchIn(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in
-                ("Rwb", "Rwb_d", "x", "xdot", "w", "x_d", "xdot_d", "w_d", "feet", "stance")]
+                ("Rwb", "Rwb_d", "x", "xdot", "w", "x_d", "xdot_d", "w_d", "feet", "stance", "joint_q")]
 
 
 class QcBatchOut(C.Structure):
-    _fields_ = [(k, C.c_void_p) for k in ("grf_body", "status", "active_set", "iterations")]
+    _fields_ = [(k, C.c_void_p) for k in ("grf_body", "status", "active_set", "iterations", "joint_tau")]
+
+
+class QcKinematics(C.Structure):
+    _fields_ = [("hip", C.c_double * 12), ("links", C.c_double * 12), ("tau_min", C.c_double), ("tau_max", C.c_double)]
 
 
 EXPORTS = ("qc_create", "qc_destroy", "qc_control_batch", "qc_control_batch_host", "qc_control",
-           "qc_last_error", "qc_kernel_name", "qc_abi_version")
+           "qc_last_error", "qc_kernel_name", "qc_abi_version", "qc_default_kinematics", "qc_set_kinematics")
 
 _lib = None
 
@@ -79,6 +83,10 @@ def load():
     lib.qc_kernel_name.argtypes = [C.c_void_p]
     lib.qc_kernel_name.restype = C.c_char_p
     lib.qc_abi_version.restype = C.c_int
+    lib.qc_default_kinematics.argtypes = [C.POINTER(QcKinematics)]
+    lib.qc_default_kinematics.restype = None
+    lib.qc_set_kinematics.argtypes = [C.c_void_p, C.POINTER(QcKinematics)]
+    lib.qc_set_kinematics.restype = C.c_int
     _lib = lib
     return lib
 

@@ -61,6 +61,23 @@ class BalanceController:
         return cls(P["mu"], P["mass"], P["fzmin"], P["fzmax"], P["Ib"], P["S"], P["W"], P["kff"],
                    P["kp_p"], P["kd_p"], P["kp_w"], P["kd_w"], **kw)
 
+    def set_kinematics(self, hip=None, links=None, tau_min=None, tau_max=None):
+        """Kinematic model of the joint_q / joint_tau extension; unspecified parts keep
+        the reference's constants (kinematics.cpp:20-47, commander_node.cpp:324-325)."""
+        k = _lib.QcKinematics()
+        self._lib.qc_default_kinematics(C.byref(k))
+        if hip is not None:
+            _fill(k.hip, hip, 12, "hip")
+        if links is not None:
+            _fill(k.links, links, 12, "links")
+        if tau_min is not None:
+            k.tau_min = float(tau_min)
+        if tau_max is not None:
+            k.tau_max = float(tau_max)
+        rc = self._lib.qc_set_kinematics(self._h, C.byref(k))
+        if rc != _lib.QC_OK:
+            raise RuntimeError(f"qc_set_kinematics failed ({rc}): {_lib.last_error()}")
+
     @property
     def kernel_name(self):
         return self._lib.qc_kernel_name(self._h).decode()
@@ -106,19 +123,26 @@ class BalanceController:
         return force_map
 
     # ------------------------------------------------------------------ batches
-    def control_batch(self, batch, warm=None, out=None, want_active_set=False, want_iterations=False, stream=None):
+    def control_batch(self, batch, warm=None, out=None, want_active_set=False, want_iterations=False, stream=None,
+                      want_torques=False):
         """n robots, device-resident.  `batch`: dict of CUDA/HIP torch tensors
         (float64, contiguous; 'stance' uint8 [n,4] or None) on this controller's
         device.  Asynchronous on `stream` (default: torch's current stream).
-        Returns dict(grf_body [n,12], status [n] int32, active_set?, iterations?)."""
+        Returns dict(grf_body [n,12], status [n] int32, active_set?, iterations?).
+        With batch['joint_q'] [n,12] the foot positions come from the reference's
+        forward kinematics (kinematics.cpp:81-103) and want_torques=True adds
+        joint_tau [n,12] = clamp(J^T f_body) for stance legs (kinematics.cpp:219-231)."""
         import torch
 
         n = batch["x"].shape[0]
         dev = torch.device("cuda", self.device)
         bi = _lib.QcBatchIn()
-        for name, k in _IN_FIELDS:
-            t = batch[name]
-            if t.dtype != torch.float64 or not t.is_contiguous() or t.device != dev or t.numel() != n * k:
+        fields = _IN_FIELDS + ((("joint_q", 12),) if batch.get("joint_q") is not None else ())
+        for name, k in fields:
+            t = batch.get(name)
+            if t is None and name == "feet" and batch.get("joint_q") is not None:
+                continue  # feet come from forward kinematics on the device
+            if t is None or t.dtype != torch.float64 or not t.is_contiguous() or t.device != dev or t.numel() != n * k:
                 raise ValueError(f"{name}: need contiguous float64 [{n},{k}] on {dev}")
             setattr(bi, name, t.data_ptr())
         st = batch.get("stance")
@@ -133,11 +157,14 @@ class BalanceController:
                 out["active_set"] = torch.empty((n,), dtype=torch.int32, device=dev)
             if want_iterations:
                 out["iterations"] = torch.empty((n,), dtype=torch.int32, device=dev)
+            if want_torques:
+                out["joint_tau"] = torch.empty((n, 12), dtype=torch.float64, device=dev)
         bo = _lib.QcBatchOut()
         bo.grf_body = out["grf_body"].data_ptr()
         bo.status = out["status"].data_ptr()
         bo.active_set = out["active_set"].data_ptr() if "active_set" in out else None
         bo.iterations = out["iterations"].data_ptr() if "iterations" in out else None
+        bo.joint_tau = out["joint_tau"].data_ptr() if "joint_tau" in out else None
         warm_ptr = None
         if warm is not None:
             if warm.dtype != torch.int32 or warm.numel() != n or not warm.is_contiguous():
@@ -149,7 +176,8 @@ class BalanceController:
             raise RuntimeError(f"qc_control_batch failed ({rc}): {_lib.last_error()}")
         return out
 
-    def plan_batch(self, batch, warm=None, out=None, want_active_set=False, want_iterations=False, stream=None):
+    def plan_batch(self, batch, warm=None, out=None, want_active_set=False, want_iterations=False, stream=None,
+                   want_torques=False):
         """Validate and marshal the arguments of control_batch() once and return
         (launch, out): `launch()` is a single C call (qc_control_batch) that can be
         issued every tick without Python-side marshalling, e.g. in a simulation or
@@ -159,10 +187,11 @@ class BalanceController:
         n = batch["x"].shape[0]
         dev = torch.device("cuda", self.device)
         first = self.control_batch(batch, warm=warm, out=out, want_active_set=want_active_set,
-                                   want_iterations=want_iterations, stream=stream)  # validates + allocates
+                                   want_iterations=want_iterations, stream=stream, want_torques=want_torques)  # validates + allocates
         bi = _lib.QcBatchIn()
-        for name, _ in _IN_FIELDS:
-            setattr(bi, name, batch[name].data_ptr())
+        for name, _ in _IN_FIELDS + (("joint_q", 12),):
+            if batch.get(name) is not None:
+                setattr(bi, name, batch[name].data_ptr())
         if batch.get("stance") is not None:
             bi.stance = batch["stance"].data_ptr()
         bo = _lib.QcBatchOut()
@@ -170,6 +199,7 @@ class BalanceController:
         bo.status = first["status"].data_ptr()
         bo.active_set = first["active_set"].data_ptr() if "active_set" in first else None
         bo.iterations = first["iterations"].data_ptr() if "iterations" in first else None
+        bo.joint_tau = first["joint_tau"].data_ptr() if "joint_tau" in first else None
         warm_ptr = warm.data_ptr() if warm is not None else None
         s = stream if stream is not None else torch.cuda.current_stream(dev)
         fn, h, sp = self._lib.qc_control_batch, self._h, C.c_void_p(s.cuda_stream)
@@ -183,12 +213,15 @@ class BalanceController:
 
         return launch, first
 
-    def control_batch_host(self, batch, warm=None, want_active_set=False, want_iterations=False):
+    def control_batch_host(self, batch, warm=None, want_active_set=False, want_iterations=False, want_torques=False):
         """n robots, numpy (host) arrays in and out; PCIe-inclusive convenience path."""
         n = batch["x"].shape[0]
         keep = []
         bi = _lib.QcBatchIn()
-        for name, k in _IN_FIELDS:
+        fields = _IN_FIELDS + ((("joint_q", 12),) if batch.get("joint_q") is not None else ())
+        for name, k in fields:
+            if batch.get(name) is None and name == "feet" and batch.get("joint_q") is not None:
+                continue
             a = np.ascontiguousarray(batch[name], dtype=np.float64)
             if a.size != n * k:
                 raise ValueError(f"{name}: expected [{n},{k}]")
@@ -204,7 +237,10 @@ class BalanceController:
             out["active_set"] = np.zeros(n, dtype=np.uint32)
         if want_iterations:
             out["iterations"] = np.zeros(n, dtype=np.int32)
+        if want_torques:
+            out["joint_tau"] = np.zeros((n, 12))
         bo = _lib.QcBatchOut()
+        bo.joint_tau = out["joint_tau"].ctypes.data if want_torques else None
         bo.grf_body = out["grf_body"].ctypes.data
         bo.status = out["status"].ctypes.data
         bo.active_set = out["active_set"].ctypes.data if want_active_set else None

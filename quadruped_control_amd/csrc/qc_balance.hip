@@ -35,7 +35,7 @@ namespace qc {
 // park their result and, once `refill_t` groups are parked, the wave flushes
 // their outputs and hands them the next robots of the chunk.  This keeps the
 // lanes busy although robots need between 1 and ~20 recalculations.
-template <class Eqp>
+template <class Eqp, bool KIN>
 struct Lane {
   static constexpr int G = Eqp::G;
   static constexpr int FPL = 4 / G;  // feet per lane
@@ -149,7 +149,7 @@ struct Lane {
   QC_DEV void load(CParams& P, const BatchIn& in, const uint32_t* __restrict__ warm, long robot, int member) {
     idx = robot;
     foot0 = member * FPL;
-    const double fin = build_wrench<FPL>(P, in, robot, foot0, Wr);
+    const double fin = build_wrench<FPL, KIN>(P, in, robot, foot0, Wr);
     stance = 0xFu;  // make_stance_gait(), gait.cpp:24-34
     if (in.stance) {
       const uint32_t sw = *reinterpret_cast<const uint32_t*>(in.stance + 4 * robot);
@@ -187,7 +187,7 @@ struct Lane {
   }
 
   // output transform, BC.cpp:218-232: fb = -Rwb^T fw for stance legs (Rwb re-read: cheaper than 18 live VGPRs)
-  QC_DEV void store(const BatchIn& in, const BatchOut& out) const {
+  QC_DEV void store(CParams& P, const BatchIn& in, const BatchOut& out) const {
     const double* Rp = in.Rwb + 9 * idx;
     double R[9];
 #pragma unroll
@@ -198,10 +198,19 @@ struct Lane {
 #pragma unroll
     for (int i = 0; i < FPL; i++) {
       const bool st = ((stance >> (foot0 + i)) & 1u) && st_out == QC_SOLVED;
+      double fb[3];
 #pragma unroll
       for (int r = 0; r < 3; r++) {
         const double v = -(R[r] * f[3 * i] + R[3 + r] * f[3 * i + 1] + R[6 + r] * f[3 * i + 2]);
-        o[3 * i + r] = st ? v : 0.0;
+        fb[r] = st ? v : 0.0;
+        o[3 * i + r] = fb[r];
+      }
+      if (KIN && out.joint_tau) {  // commander_node.cpp:511-526: tau = clamp(J^T f, tau_min, tau_max)
+        double tau[3];
+        leg_jt_force(P, foot0 + i, leg_trig(in.joint_q + 12 * idx + 3 * (foot0 + i)), fb, tau);
+        double* to = out.joint_tau + 12 * idx + 3 * (foot0 + i);
+#pragma unroll
+        for (int r = 0; r < 3; r++) to[r] = st ? fmin(fmax(tau[r], P.tau_min), P.tau_max) : 0.0;
       }
       word |= encode_foot(C.sx[i], C.sy[i], C.sz[i]) << (6 * (foot0 + i));
     }
@@ -214,7 +223,7 @@ struct Lane {
   }
 };
 
-template <class Eqp, int MIN_WAVES_PER_SIMD>
+template <class Eqp, bool KIN, int MIN_WAVES_PER_SIMD>
 __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const DevParams* __restrict__ Pg, const long n, const BatchIn in,
                                                                          const uint32_t* __restrict__ warm, const BatchOut out, const long chunk,
                                                                          const int refill_t) {
@@ -223,7 +232,7 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
   long cursor = (long)blockIdx.x * chunk;  // wave-uniform
   const long end = cursor + chunk < n ? cursor + chunk : n;
   const int member = threadIdx.x & (G - 1);
-  Lane<Eqp> L;
+  Lane<Eqp, KIN> L;
   L.idx = -1;
   L.foot0 = member * (4 / G);
   Eqp eqp(qc_lds + threadIdx.x);
@@ -235,7 +244,11 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
     const long remaining = end - cursor;
     const bool refill = remaining > 0 && (n_free >= refill_t || busy_mask == 0);
     if (refill || busy_mask == 0) {
-      if (parked) { L.store(in, out); parked = false; }
+      if (parked) {
+        CParams& P = *QC_PARAMS_HERE(Pg);
+        L.store(P, in, out);
+        parked = false;
+      }
     }
     if (refill) {
       const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(~busy_mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)~busy_mask, 0)) / G;
@@ -330,6 +343,32 @@ const char* qc_kernel_name(const qc_handle* h) {
   return h->diag_w ? (h->uniform ? "diagW-6x6-uniform" : "diagW-6x6") : "dense-12x12";
 }
 
+void qc_default_kinematics(qc_kinematics* k) {
+  if (!k) return;
+  // QuadrupedKinematics::QuadrupedKinematics(), kinematics.cpp:20-47
+  const double xbh = 0.196, ybh = 0.050, zbh = 0.0, l1 = 0.077, l2 = 0.211, l3 = 0.230;
+  const double hip[12] = {-xbh, ybh, zbh, xbh, ybh, zbh, -xbh, -ybh, zbh, xbh, -ybh, zbh};  // RL FL RR FR
+  const double links[12] = {l1, -l2, -l3, l1, -l2, -l3, -l1, -l2, -l3, -l1, -l2, -l3};    // left, left, right, right
+  std::memcpy(k->hip, hip, sizeof(hip));
+  std::memcpy(k->links, links, sizeof(links));
+  k->tau_min = -20.0;  // commander_node.cpp:324-325
+  k->tau_max = 20.0;
+}
+
+int qc_set_kinematics(qc_handle* h, const qc_kinematics* kin) {
+  if (!h) return fail(QC_ERR_INVALID, "qc_set_kinematics: null handle");
+  qc_kinematics k;
+  if (kin) k = *kin; else qc_default_kinematics(&k);
+  if (!(k.tau_min <= k.tau_max)) return fail(QC_ERR_INVALID, "qc_set_kinematics: need tau_min <= tau_max");
+  std::memcpy(h->dp.hip, k.hip, sizeof(k.hip));
+  std::memcpy(h->dp.links, k.links, sizeof(k.links));
+  h->dp.tau_min = k.tau_min;
+  h->dp.tau_max = k.tau_max;
+  QC_HIP(hipSetDevice(h->device));
+  QC_HIP(hipMemcpy(h->d_params, &h->dp, sizeof(qc::DevParams), hipMemcpyHostToDevice));  // synchronous: no launch races it
+  return QC_OK;
+}
+
 int qc_create(const qc_params* p, int device, qc_handle** out) {
   if (!p || !out) return fail(QC_ERR_INVALID, "qc_create: null argument");
   *out = nullptr;
@@ -395,6 +434,14 @@ int qc_create(const qc_params* p, int device, qc_handle** out) {
   std::memcpy(d.kd_p, p->kd_p, sizeof(d.kd_p));
   std::memcpy(d.kp_w, p->kp_w, sizeof(d.kp_w));
   std::memcpy(d.kd_w, p->kd_w, sizeof(d.kd_w));
+  {
+    qc_kinematics k;
+    qc_default_kinematics(&k);
+    std::memcpy(d.hip, k.hip, sizeof(k.hip));
+    std::memcpy(d.links, k.links, sizeof(k.links));
+    d.tau_min = k.tau_min;
+    d.tau_max = k.tau_max;
+  }
   d.tol_d = 1e-12;  // relative to 1+|grad|_inf: W ~ 1e-5 makes the primal very sensitive to a wrongly kept weakly-active face
   if (const char* e = std::getenv("QC_TOL_D")) d.tol_d = std::atof(e);  // development knob
   d.max_iter = p->max_iter > 0 ? p->max_iter : 200;
@@ -429,12 +476,14 @@ void qc_destroy(qc_handle* h) {
 int qc_control_batch(qc_handle* h, size_t n, const qc_batch_in* in, const uint32_t* warm, const qc_batch_out* out, void* stream) {
   if (!h || !in || !out) return fail(QC_ERR_INVALID, "qc_control_batch: null argument");
   if (n == 0) return QC_OK;
-  if (!in->Rwb || !in->Rwb_d || !in->x || !in->xdot || !in->w || !in->x_d || !in->xdot_d || !in->w_d || !in->feet)
+  if (!in->Rwb || !in->Rwb_d || !in->x || !in->xdot || !in->w || !in->x_d || !in->xdot_d || !in->w_d || (!in->feet && !in->joint_q))
     return fail(QC_ERR_INVALID, "qc_control_batch: null input array");
   if (!out->grf_body || !out->status) return fail(QC_ERR_INVALID, "qc_control_batch: grf_body and status are required");
+  if (out->joint_tau && !in->joint_q) return fail(QC_ERR_INVALID, "qc_control_batch: joint_tau needs joint_q");
   QC_HIP(hipSetDevice(h->device));
-  qc::BatchIn bi{in->Rwb, in->Rwb_d, in->x, in->xdot, in->w, in->x_d, in->xdot_d, in->w_d, in->feet, in->stance};
-  qc::BatchOut bo{out->grf_body, out->status, out->active_set, out->iterations};
+  const bool kin = in->joint_q != nullptr;
+  qc::BatchIn bi{in->Rwb, in->Rwb_d, in->x, in->xdot, in->w, in->x_d, in->xdot_d, in->w_d, in->feet, in->stance, in->joint_q};
+  qc::BatchOut bo{out->grf_body, out->status, out->active_set, out->iterations, out->joint_tau};
   // One wave per 64-thread block; a group of G lanes per robot.  The group
   // width trades latency for throughput: G = 4 (foot per lane) cuts the serial
   // length of one recalculation (707 instead of 1330 instructions) and is used
@@ -459,8 +508,11 @@ int qc_control_batch(qc_handle* h, size_t n, const qc_batch_in* in, const uint32
   const unsigned blocks = (unsigned)(((long)n + chunk - 1) / chunk);
   const int refill_t = h->refill_t > 0 ? (h->refill_t + G - 1) / G : 1;
   const hipStream_t st = (hipStream_t)stream;
-#define QC_LAUNCH(EQP, MINW, LDS) \
-  qc::balance_kernel<EQP, MINW><<<dim3(blocks), dim3(64), LDS, st>>>(h->d_params, (long)n, bi, warm, bo, chunk, refill_t)
+#define QC_LAUNCH(EQP, MINW, LDS)                                                                                                    \
+  do {                                                                                                                              \
+    if (kin) qc::balance_kernel<EQP, true, MINW><<<dim3(blocks), dim3(64), LDS, st>>>(h->d_params, (long)n, bi, warm, bo, chunk, refill_t);  \
+    else qc::balance_kernel<EQP, false, MINW><<<dim3(blocks), dim3(64), LDS, st>>>(h->d_params, (long)n, bi, warm, bo, chunk, refill_t);     \
+  } while (0)
   if (!h->diag_w) QC_LAUNCH(qc::EqpDense, 1, 78 * 64 * sizeof(double));
   else if (!h->uniform) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<false, 1>), 2, 0);
   else if (G == 4) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<true, 4>), 2, 0);
@@ -475,13 +527,14 @@ int qc_control_batch(qc_handle* h, size_t n, const qc_batch_in* in, const uint32
 int qc_control_batch_host(qc_handle* h, size_t n, const qc_batch_in* in, const uint32_t* warm, const qc_batch_out* out) {
   if (!h || !in || !out) return fail(QC_ERR_INVALID, "qc_control_batch_host: null argument");
   if (n == 0) return QC_OK;
-  if (!in->Rwb || !in->Rwb_d || !in->x || !in->xdot || !in->w || !in->x_d || !in->xdot_d || !in->w_d || !in->feet)
+  if (!in->Rwb || !in->Rwb_d || !in->x || !in->xdot || !in->w || !in->x_d || !in->xdot_d || !in->w_d || (!in->feet && !in->joint_q))
     return fail(QC_ERR_INVALID, "qc_control_batch_host: null input array");
+  if (out->joint_tau && !in->joint_q) return fail(QC_ERR_INVALID, "qc_control_batch_host: joint_tau needs joint_q");
   if (!out->grf_body || !out->status) return fail(QC_ERR_INVALID, "qc_control_batch_host: grf_body and status are required");
   QC_HIP(hipSetDevice(h->device));
   if (!h->stream) QC_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   // layout (all 8-byte aligned): 48 doubles in, 12 doubles out, 4 x 4-byte words
-  const size_t per = 48 * 8 + 12 * 8 + 4 * 4 + 8;
+  const size_t per = 48 * 8 + 12 * 8 + 4 * 4 + 8 + 12 * 8 + 12 * 8;
   const size_t need = n * per + 256;
   if (need > h->stage_bytes) {
     if (h->stage) QC_HIP(hipFree(h->stage));
@@ -496,9 +549,17 @@ int qc_control_batch_host(qc_handle* h, size_t n, const qc_batch_in* in, const u
   const double* src[9] = {in->Rwb, in->Rwb_d, in->x, in->xdot, in->w, in->x_d, in->xdot_d, in->w_d, in->feet};
   double* dptr[9];
   for (int k = 0; k < 9; k++) {
+    dptr[k] = nullptr;
+    if (!src[k]) continue;  // feet may be absent when joint_q is given
     dptr[k] = (double*)carve(n * szs[k] * 8);
     QC_HIP(hipMemcpyAsync(dptr[k], src[k], n * szs[k] * 8, hipMemcpyHostToDevice, h->stream));
   }
+  double* d_q = nullptr;
+  if (in->joint_q) {
+    d_q = (double*)carve(n * 12 * 8);
+    QC_HIP(hipMemcpyAsync(d_q, in->joint_q, n * 12 * 8, hipMemcpyHostToDevice, h->stream));
+  }
+  double* d_tau = out->joint_tau ? (double*)carve(n * 12 * 8) : nullptr;
   uint8_t* d_st = nullptr;
   if (in->stance) {
     d_st = (uint8_t*)carve(n * 4);
@@ -514,14 +575,15 @@ int qc_control_batch_host(qc_handle* h, size_t n, const qc_batch_in* in, const u
   uint32_t* d_act = out->active_set ? (uint32_t*)carve(n * 4) : nullptr;
   int32_t* d_it = out->iterations ? (int32_t*)carve(n * 4) : nullptr;
   if (off > h->stage_bytes) return fail(QC_ERR_INVALID, "qc_control_batch_host: staging overflow");
-  qc_batch_in din{dptr[0], dptr[1], dptr[2], dptr[3], dptr[4], dptr[5], dptr[6], dptr[7], dptr[8], d_st};
-  qc_batch_out dout{d_grf, d_status, d_act, d_it};
+  qc_batch_in din{dptr[0], dptr[1], dptr[2], dptr[3], dptr[4], dptr[5], dptr[6], dptr[7], dptr[8], d_st, d_q};
+  qc_batch_out dout{d_grf, d_status, d_act, d_it, d_tau};
   int rc = qc_control_batch(h, n, &din, d_warm, &dout, h->stream);
   if (rc != QC_OK) return rc;
   QC_HIP(hipMemcpyAsync(out->grf_body, d_grf, n * 12 * 8, hipMemcpyDeviceToHost, h->stream));
   QC_HIP(hipMemcpyAsync(out->status, d_status, n * 4, hipMemcpyDeviceToHost, h->stream));
   if (d_act) QC_HIP(hipMemcpyAsync(out->active_set, d_act, n * 4, hipMemcpyDeviceToHost, h->stream));
   if (d_it) QC_HIP(hipMemcpyAsync(out->iterations, d_it, n * 4, hipMemcpyDeviceToHost, h->stream));
+  if (d_tau) QC_HIP(hipMemcpyAsync(out->joint_tau, d_tau, n * 12 * 8, hipMemcpyDeviceToHost, h->stream));
   QC_HIP(hipStreamSynchronize(h->stream));
   return QC_OK;
 }
@@ -529,8 +591,8 @@ int qc_control_batch_host(qc_handle* h, size_t n, const qc_batch_in* in, const u
 int qc_control(qc_handle* h, const double* Rwb, const double* Rwb_d, const double* x, const double* xdot,
                const double* w, const double* x_d, const double* xdot_d, const double* w_d, const double* feet,
                const uint8_t* stance, double* grf_body, int32_t* status) {
-  qc_batch_in in{Rwb, Rwb_d, x, xdot, w, x_d, xdot_d, w_d, feet, stance};
-  qc_batch_out out{grf_body, status, nullptr, nullptr};
+  qc_batch_in in{Rwb, Rwb_d, x, xdot, w, x_d, xdot_d, w_d, feet, stance, nullptr};
+  qc_batch_out out{grf_body, status, nullptr, nullptr, nullptr};
   return qc_control_batch_host(h, 1, &in, nullptr, &out);
 }
 

@@ -41,6 +41,10 @@ struct DevParams {
   double inv_w_u;      // 1 / w
   double inv_bz_u[3];  // [|sx|+|sy|] 1 / (w (1 + mu^2 k))
   double kff[6], kp_p[3], kd_p[3], kp_w[3], kd_w[3];
+  // kinematic model (joint_q / joint_tau extension): kinematics.cpp:20-47, commander_node.cpp:324-325
+  double hip[12];      // [leg][xyz] base -> hip
+  double links[12];    // [leg][l1,l2,l3] signed
+  double tau_min, tau_max;
   double tol_d;        // relative multiplier tolerance
   int max_iter;
   int pad;
@@ -62,12 +66,14 @@ typedef const __attribute__((address_space(4))) DevParams CParams;
 struct BatchIn {
   const double *Rwb, *Rwb_d, *x, *xdot, *w, *x_d, *xdot_d, *w_d, *feet;
   const uint8_t* stance;
+  const double* joint_q;
 };
 struct BatchOut {
   double* grf_body;
   int32_t* status;
   uint32_t* active_set;
   int32_t* iterations;
+  double* joint_tau;
 };
 
 // ------------------------------------------------------------ lane groups
@@ -190,9 +196,45 @@ QC_DEV void load9(const double* __restrict__ p, long idx, double (&v)[9]) {
   for (int k = 0; k < 9; k++) v[k] = q[k];
 }
 
+// Leg kinematics of the reference (kinematics.cpp), one leg: sines/cosines of
+// (t1, t2, t2+t3) from three sincos calls and the angle-addition formulas.
+struct LegTrig {
+  double s1, c1, s2, c2, s23, c23;
+};
+QC_DEV LegTrig leg_trig(const double* __restrict__ q) {
+  LegTrig t;
+  double s3, c3;
+  sincos(q[0], &t.s1, &t.c1);
+  sincos(q[1], &t.s2, &t.c2);
+  sincos(q[2], &s3, &c3);
+  t.s23 = t.s2 * c3 + t.c2 * s3;
+  t.c23 = t.c2 * c3 - t.s2 * s3;
+  return t;
+}
+// QuadrupedKinematics::forwardKinematics(leg, q), kinematics.cpp:81-103; `leg` may be a runtime value
+QC_DEV void leg_fk(CParams& P, int leg, const LegTrig& t, double (&p)[3]) {
+  const double l1 = P.links[3 * leg], l2 = P.links[3 * leg + 1], l3 = P.links[3 * leg + 2];
+  p[0] = l2 * t.s2 + l3 * t.s23 + P.hip[3 * leg];
+  p[1] = l1 * t.c1 - l2 * t.s1 * t.c2 - l3 * t.s1 * t.c23 + P.hip[3 * leg + 1];
+  p[2] = l1 * t.s1 + l2 * t.c1 * t.c2 + l3 * t.c1 * t.c23 + P.hip[3 * leg + 2];
+}
+// tau = J^T f with J = QuadrupedKinematics::legJacobian (kinematics.cpp:162-188), kinematics.cpp:219-231
+QC_DEV void leg_jt_force(CParams& P, int leg, const LegTrig& t, const double (&f)[3], double (&tau)[3]) {
+  const double l1 = P.links[3 * leg], l2 = P.links[3 * leg + 1], l3 = P.links[3 * leg + 2];
+  const double a = l2 * t.c2 + l3 * t.c23;  // jac(0,1)
+  const double b = l2 * t.s2 + l3 * t.s23;
+  const double j01 = a, j02 = l3 * t.c23;
+  const double j10 = -l1 * t.s1 - a * t.c1, j11 = b * t.s1, j12 = l3 * t.s1 * t.s23;
+  const double j20 = l1 * t.c1 - a * t.s1, j21 = -b * t.c1, j22 = -l3 * t.s23 * t.c1;
+  tau[0] = j10 * f[1] + j20 * f[2];  // jac(0,0) = 0
+  tau[1] = j01 * f[0] + j11 * f[1] + j21 * f[2];
+  tau[2] = j02 * f[0] + j12 * f[1] + j22 * f[2];
+}
+
 // K0 + K2 + K3 of SURVEY.md 2.2: gather, PD wrench law, SRB dynamics rhs.
-// `foot0` = first foot owned by this lane.  Returns 0.0 iff every input was finite.
-template <int FPL>
+// `foot0` = first foot owned by this lane; KIN: foot positions from joint_q by
+// forward kinematics instead of the `feet` array.  Returns 0.0 iff every input was finite.
+template <int FPL, bool KIN>
 QC_DEV double build_wrench(CParams& P, const BatchIn& in, long idx, int foot0, Wrench<FPL>& W) {
   double R[9], Rd[9], x[3], xd[3], xdot[3], xdotd[3], w[3], wd[3];
   load9(in.Rwb, idx, R);
@@ -203,10 +245,15 @@ QC_DEV double build_wrench(CParams& P, const BatchIn& in, long idx, int foot0, W
   load3(in.xdot_d, idx, xdotd);
   load3(in.w, idx, w);
   load3(in.w_d, idx, wd);
-  const double* fp = in.feet + 12 * idx + 3 * foot0;
+  const double* fp = (KIN ? in.joint_q : in.feet) + 12 * idx + 3 * foot0;
 #pragma unroll
   for (int i = 0; i < FPL; i++) {
     double p0 = fp[3 * i], p1 = fp[3 * i + 1], p2 = fp[3 * i + 2];
+    if (KIN) {  // commander_node.cpp:383-384: foot_actual_map = kinematics.forwardKinematics(joint_states_map)
+      double pb[3];
+      leg_fk(P, foot0 + i, leg_trig(fp + 3 * i), pb);
+      p0 = pb[0]; p1 = pb[1]; p2 = pb[2];
+    }
 #pragma unroll
     for (int k = 0; k < 3; k++) W.r[i][k] = R[3 * k] * p0 + R[3 * k + 1] * p1 + R[3 * k + 2] * p2;  // BC.cpp:244-248
   }

@@ -160,3 +160,19 @@ def shard_bounds(n, rank, world):
     base, rem = divmod(n, world)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+# ---- inputs for the fused tick (forward kinematics -> control -> J^T torque) ----
+NOMINAL_JOINTS = np.array([0.0, 0.8, -1.6])  # hip, thigh, calf: feet ~0.3 m below the hips
+
+
+def with_joint_angles(batch, seed=0x5EED0006, start=0):
+    """Replace the `feet` of a batch by joint angles: joint_q [n,12] (RL,FL,RR,FR x hip,thigh,calf),
+    nominal stance +- 0.25 rad per joint.  The matching foot positions are whatever the
+    reference's forward kinematics (kinematics.cpp:81-103) makes of them."""
+    n = batch["x"].shape[0]
+    idx = np.arange(start, start + n, dtype=np.uint64)
+    q = np.tile(NOMINAL_JOINTS, 4)[None] + _uvec(seed, idx, 40, 12, -0.25, 0.25)
+    out = {k: v for k, v in batch.items() if k != "feet"}
+    out["joint_q"] = np.ascontiguousarray(q)
+    return out

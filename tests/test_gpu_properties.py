@@ -217,3 +217,34 @@ def test_dense_W_path(q, monkeypatch):
     assert (o["status"] == 0).all() and (st2 == 0).all()
     scale2 = np.maximum(1.0, np.abs(ref2).max(axis=1, keepdims=True))
     assert np.max(np.abs(o["grf_body"] - ref2) / scale2) < 1e-6
+
+
+@pytest.mark.parametrize("n", [1000, 40000])  # G = 4 and G = 2 lane groups
+def test_fused_tick_fk_and_torques(q, n):
+    """joint_q in, joint_tau out (SURVEY 8f rows 1+2): device FK -> control -> clamp(J^T f)
+    against the oracle's composition, and against the unfused path fed with the oracle's feet."""
+    from oracle import c_oracle as O
+    from quadruped_control_amd import workloads as W
+
+    P = q.cheetah_params(0.6)
+    b = W.with_joint_angles(W.config3(n))
+    ctl = q.BalanceController.from_params(P)
+    o = ctl.control_batch_host(b, want_torques=True)
+    ref = O.tick_batch(P, b, threads=8)
+    assert (o["status"] == 0).all() and (ref["status"] == 0).all()
+    scale = np.maximum(1.0, np.abs(ref["grf_body"]).max(axis=1, keepdims=True))
+    assert np.max(np.abs(o["grf_body"] - ref["grf_body"]) / scale) < 1e-6
+    assert np.max(np.abs(o["joint_tau"] - ref["joint_tau"])) < 1e-6 * 20.0
+    assert np.all(np.abs(o["joint_tau"]) <= 20.0) and np.all(o["joint_tau"][np.repeat(b["stance"] == 0, 3, axis=1)] == 0.0)
+    assert (np.abs(o["joint_tau"]) == 20.0).any()  # the +-20 N m clamp is exercised
+    # unfused path with the oracle's foot positions gives the same forces
+    b2 = {k: v for k, v in b.items() if k != "joint_q"}
+    b2["feet"] = ref["feet"]
+    o2 = ctl.control_batch_host(b2)
+    assert np.max(np.abs(o2["grf_body"] - o["grf_body"]) / scale) < 1e-8
+    # custom kinematic model / torque limits
+    ctl.set_kinematics(tau_min=-5.0, tau_max=7.0)
+    o3 = ctl.control_batch_host(b, want_torques=True)
+    assert o3["joint_tau"].min() >= -5.0 and o3["joint_tau"].max() <= 7.0
+    with pytest.raises(RuntimeError, match="joint_tau needs joint_q"):
+        ctl.control_batch_host(b2, want_torques=True)

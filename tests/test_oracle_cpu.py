@@ -122,3 +122,41 @@ def test_failure_and_edge_cases():
     P0 = dict(P); P0["fzmin"] = 0.0
     grf, st, _ = O.control_batch(P0, W.config3(64))
     assert (st == 0).all()
+
+
+def test_kinematics_against_reference_notebook():
+    """The ONLY known answers the reference holds: the printed
+    FK positions and Jacobians of scripts/kinematics/quadruped_kinematics.ipynb."""
+    with open(os.path.join(os.path.dirname(__file__), "golden", "kinematics_notebook.json")) as f:
+        g = json.load(f)
+    q = np.array(g["q"])
+    for leg, name in enumerate(R.LEG_NAMES):
+        if name in g["fk"]:
+            np.testing.assert_allclose(O.leg_fk(leg, q), g["fk"][name], atol=6e-9)  # 8 printed digits
+        np.testing.assert_allclose(O.leg_jacobian(leg, q), np.array(g["jacobian"][name]), atol=6e-9)
+    # Jacobian == derivative of FK (central differences)
+    rng = np.random.default_rng(7)
+    for _ in range(20):
+        qq = rng.uniform(-1.5, 1.5, 3)
+        for leg in range(4):
+            J = O.leg_jacobian(leg, qq)
+            h = 1e-6
+            num = np.stack([(O.leg_fk(leg, qq + h * e) - O.leg_fk(leg, qq - h * e)) / (2 * h) for e in np.eye(3)], axis=1)
+            np.testing.assert_allclose(J, num, atol=1e-8)
+
+
+def test_tick_composition():
+    """oracle_tick_batch == FK -> control -> clamp(J^T f) composed by hand."""
+    P = R.cheetah_params(0.6)
+    b = W.with_joint_angles(W.config3(64))
+    t = O.tick_batch(P, b)
+    feet = np.stack([np.concatenate([O.leg_fk(leg, b["joint_q"][i, 3 * leg:3 * leg + 3]) for leg in range(4)]) for i in range(64)])
+    np.testing.assert_allclose(t["feet"], feet, atol=1e-15)
+    b2 = dict(b); b2["feet"] = feet
+    grf, st, _ = O.control_batch(P, b2)
+    np.testing.assert_array_equal(t["grf_body"], grf)
+    for i in range(64):
+        for leg in range(4):
+            tau = O.leg_jacobian(leg, b["joint_q"][i, 3 * leg:3 * leg + 3]).T @ grf[i, 3 * leg:3 * leg + 3]
+            exp = np.clip(tau, -20.0, 20.0) if b["stance"][i, leg] else np.zeros(3)
+            np.testing.assert_allclose(t["joint_tau"][i, 3 * leg:3 * leg + 3], exp, atol=1e-12)
