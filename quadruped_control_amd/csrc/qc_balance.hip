@@ -86,16 +86,23 @@ struct Lane {
     const bool pd = eqp.solve(P, Wr, C, stance, foot0, fh, g);
     const bool fresh = !have_f;
     have_f = true;
-    // (a) fresh robot: clamp f^ into the frusta
+    // (a) fresh robot: clamp f^ into the frusta.  Fresh robots exist only right
+    // after a (re)fill, so the whole block sits behind a wave-uniform branch.
     double fc[3 * FPL];
     Cube<FPL> Cc;
-    int ch = 0;
+    bool changed = false;
 #pragma unroll
     for (int i = 0; i < FPL; i++) {
       fc[3 * i] = fh[3 * i]; fc[3 * i + 1] = fh[3 * i + 1]; fc[3 * i + 2] = fh[3 * i + 2];
-      ch |= (int)clamp_foot(P.mu, lo(P, i), hi(P, i), fc[3 * i], fc[3 * i + 1], fc[3 * i + 2], Cc.sx[i], Cc.sy[i], Cc.sz[i]);
+      Cc.sx[i] = Cc.sy[i] = Cc.sz[i] = 0;
     }
-    const bool changed = group_or<G>(ch) != 0;
+    if (__builtin_amdgcn_ballot_w64(fresh) != 0) {
+      int ch = 0;
+#pragma unroll
+      for (int i = 0; i < FPL; i++)
+        ch |= (int)clamp_foot(P.mu, lo(P, i), hi(P, i), fc[3 * i], fc[3 * i + 1], fc[3 * i + 2], Cc.sx[i], Cc.sy[i], Cc.sz[i]);
+      changed = group_or<G>(ch) != 0;
+    }
     // (b) otherwise: ratio test over the faces outside the working set (tree min, face code in the low bits)
     double cand[6 * FPL];
 #pragma unroll

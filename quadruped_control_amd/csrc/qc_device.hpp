@@ -422,11 +422,17 @@ QC_DEV bool eqp_diagw(CParams& P, const Wrench<4 / G>& Wr, const Cube<4 / G>& C,
 #pragma unroll
   for (int k = 0; k < 6; k++) rhs[k] = 0.0;
 
+  // Face coefficients: with 1-2 feet per lane they stay live across the
+  // factorisation (12-24 VGPRs); with 4 feet per lane (G = 1) they are
+  // recomputed in pass 2 instead, registers matter more there.
+  constexpr bool KEEP = FPL <= 2;
+  FootCoef kc[FPL];
   // pass 1: this lane's part of sum_i A~_i B_i^-1 A~_i^T and of A p
 #pragma unroll
   for (int i = 0; i < FPL; i++) {
     const bool st = (stance >> (foot0 + i)) & 1u;
     const FootCoef k = foot_coef<UNIFORM>(P, C.sx[i], C.sy[i], C.sz[i], st, G == 1 ? i : 0);
+    if (KEEP) kc[i] = k;
     const double rx = Wr.r[i][0], ry = Wr.r[i][1], rz = Wr.r[i][2];
     double q[6];
     q[0] = k.mx; q[1] = k.my; q[2] = 1.0;
@@ -508,13 +514,11 @@ QC_DEV bool eqp_diagw(CParams& P, const Wrench<4 / G>& Wr, const Cube<4 / G>& C,
     v[k] = t * M[MI(k, k)];
   }
 #undef MI
-  // pass 2: forces and gradient of this lane's feet (face coefficients are
-  // recomputed, not kept live across the factorisation: registers matter
-  // more than ~12 selects per foot)
+  // pass 2: forces and gradient of this lane's feet
 #pragma unroll
   for (int i = 0; i < FPL; i++) {
     const bool st = (stance >> (foot0 + i)) & 1u;
-    const FootCoef k = foot_coef<UNIFORM>(P, C.sx[i], C.sy[i], C.sz[i], st, G == 1 ? i : 0);
+    const FootCoef k = KEEP ? kc[i] : foot_coef<UNIFORM>(P, C.sx[i], C.sy[i], C.sz[i], st, G == 1 ? i : 0);
     const double rx = Wr.r[i][0], ry = Wr.r[i][1], rz = Wr.r[i][2];
     const double ax = v[0] + v[4] * rz - v[5] * ry;  // (A_i^T v)_x
     const double ay = v[1] + v[5] * rx - v[3] * rz;
