@@ -75,10 +75,10 @@ def time_steps(ctl, dev_batch, warm, out, steps, warmup, dist=None):
         launch()
     ev1.record()
     torch.cuda.synchronize()
+    wall = time.perf_counter() - t0  # this rank's K steps; the caller takes the MAX over ranks
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
+        torch.cuda.synchronize()
     return wall, ev0.elapsed_time(ev1) * 1e-3
 
 

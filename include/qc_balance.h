@@ -65,6 +65,14 @@ typedef struct qc_batch_in {
    * kinematics (kinematics.cpp:81-103, what commander_node.cpp:383-384 does before control()) and `feet`
    * is ignored (may be NULL). */
   const double* joint_q;
+  /* ABI v2, optional.  Per-leg gait phases [n][4] in [0,1) (GaitScheduler::phases_, gait.cpp:113-123).
+   * When given (and `stance` is NULL) the contact state is derived on the device by the reference's rule
+   * (GaitScheduler::phase, gait.cpp:125-134): stance iff 0 <= phase <= stance_phase, each comparison with the
+   * 1e-12 slack of math::almost_equal.  `gait_duty` [n] = stance_phase = t_stance / (t_swing + t_stance)
+   * (gait.cpp:45) per robot, or NULL to use the value installed with qc_set_gait (default 0.8/0.98,
+   * mit_cheetah_config.yaml:17-18). */
+  const double* gait_phase;
+  const double* gait_duty;
 } qc_batch_in;
 
 /* Replaces the returned ForceMap (types.hpp:119; balance_controller.cpp:218-232). */
@@ -134,6 +142,8 @@ int qc_control(qc_handle* h, const double* Rwb, const double* Rwb_d, const doubl
 /* Kinematic model used by the joint_q / joint_tau extension; NULL restores the reference's constants. */
 void qc_default_kinematics(qc_kinematics* out);
 int qc_set_kinematics(qc_handle* h, const qc_kinematics* kin);
+/* Default stance_phase for qc_batch_in.gait_phase: t_stance / (t_swing + t_stance), GaitScheduler ctor gait.cpp:36-46. */
+int qc_set_gait(qc_handle* h, double t_swing, double t_stance);
 
 /* Thread-local message of the last failing call (ROS_ERROR replacement,
  * balance_controller.cpp:157,184,199,214). */

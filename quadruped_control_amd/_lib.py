@@ -26,7 +26,7 @@ class QcParams(C.Structure):
 
 class QcBatchIn(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in
-                ("Rwb", "Rwb_d", "x", "xdot", "w", "x_d", "xdot_d", "w_d", "feet", "stance", "joint_q")]
+                ("Rwb", "Rwb_d", "x", "xdot", "w", "x_d", "xdot_d", "w_d", "feet", "stance", "joint_q", "gait_phase", "gait_duty")]
 
 
 class QcBatchOut(C.Structure):
@@ -38,7 +38,7 @@ class QcKinematics(C.Structure):
 
 
 EXPORTS = ("qc_create", "qc_destroy", "qc_control_batch", "qc_control_batch_host", "qc_control",
-           "qc_last_error", "qc_kernel_name", "qc_abi_version", "qc_default_kinematics", "qc_set_kinematics")
+           "qc_last_error", "qc_kernel_name", "qc_abi_version", "qc_default_kinematics", "qc_set_kinematics", "qc_set_gait")
 
 _lib = None
 
@@ -87,6 +87,8 @@ def load():
     lib.qc_default_kinematics.restype = None
     lib.qc_set_kinematics.argtypes = [C.c_void_p, C.POINTER(QcKinematics)]
     lib.qc_set_kinematics.restype = C.c_int
+    lib.qc_set_gait.argtypes = [C.c_void_p, C.c_double, C.c_double]
+    lib.qc_set_gait.restype = C.c_int
     _lib = lib
     return lib
 

@@ -78,6 +78,12 @@ class BalanceController:
         if rc != _lib.QC_OK:
             raise RuntimeError(f"qc_set_kinematics failed ({rc}): {_lib.last_error()}")
 
+    def set_gait(self, t_swing, t_stance):
+        """Default stance_phase = t_stance / (t_swing + t_stance) (gait.cpp:36-46) of the on-device contact rule."""
+        rc = self._lib.qc_set_gait(self._h, float(t_swing), float(t_stance))
+        if rc != _lib.QC_OK:
+            raise RuntimeError(f"qc_set_gait failed ({rc}): {_lib.last_error()}")
+
     @property
     def kernel_name(self):
         return self._lib.qc_kernel_name(self._h).decode()
@@ -150,6 +156,12 @@ class BalanceController:
             if st.dtype != torch.uint8 or not st.is_contiguous() or st.numel() != n * 4 or st.device != dev:
                 raise ValueError("stance: need contiguous uint8 [n,4]")
             bi.stance = st.data_ptr()
+        for name, k in (("gait_phase", 4), ("gait_duty", 1)):  # on-device contact rule (gait.cpp:125-134)
+            t = batch.get(name)
+            if t is not None:
+                if t.dtype != torch.float64 or not t.is_contiguous() or t.numel() != n * k or t.device != dev:
+                    raise ValueError(f"{name}: need contiguous float64 [{n},{k}] on {dev}")
+                setattr(bi, name, t.data_ptr())
         if out is None:
             out = {"grf_body": torch.empty((n, 12), dtype=torch.float64, device=dev),
                    "status": torch.empty((n,), dtype=torch.int32, device=dev)}
@@ -192,8 +204,9 @@ class BalanceController:
         for name, _ in _IN_FIELDS + (("joint_q", 12),):
             if batch.get(name) is not None:
                 setattr(bi, name, batch[name].data_ptr())
-        if batch.get("stance") is not None:
-            bi.stance = batch["stance"].data_ptr()
+        for name in ("stance", "gait_phase", "gait_duty"):
+            if batch.get(name) is not None:
+                setattr(bi, name, batch[name].data_ptr())
         bo = _lib.QcBatchOut()
         bo.grf_body = first["grf_body"].data_ptr()
         bo.status = first["status"].data_ptr()
@@ -232,6 +245,11 @@ class BalanceController:
             st = np.ascontiguousarray(st, dtype=np.uint8)
             keep.append(st)
             bi.stance = st.ctypes.data
+        for name in ("gait_phase", "gait_duty"):
+            if batch.get(name) is not None:
+                a = np.ascontiguousarray(batch[name], dtype=np.float64)
+                keep.append(a)
+                setattr(bi, name, a.ctypes.data)
         out = {"grf_body": np.zeros((n, 12)), "status": np.zeros(n, dtype=np.int32)}
         if want_active_set:
             out["active_set"] = np.zeros(n, dtype=np.uint32)

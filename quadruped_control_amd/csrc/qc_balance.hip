@@ -161,6 +161,17 @@ struct Lane {
     if (in.stance) {
       const uint32_t sw = *reinterpret_cast<const uint32_t*>(in.stance + 4 * robot);
       stance = ((sw & 0xFFu) ? 1u : 0u) | ((sw & 0xFF00u) ? 2u : 0u) | ((sw & 0xFF0000u) ? 4u : 0u) | ((sw & 0xFF000000u) ? 8u : 0u);
+    } else if (in.gait_phase) {
+      // GaitScheduler::phase(), gait.cpp:125-134 (almost_equal = |a-b| < 1e-12, math/numerics.cpp:18-21)
+      const double duty = in.gait_duty ? in.gait_duty[robot] : P.stance_phase;
+      stance = 0;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const double ph = in.gait_phase[4 * robot + i];
+        const bool ge0 = (ph > 0.0) || (fabs(ph) < 1.0e-12);
+        const bool le = (ph < duty) || (fabs(ph - duty) < 1.0e-12);
+        stance |= (ge0 && le) ? (1u << i) : 0u;
+      }
     }
 #pragma unroll
     for (int i = 0; i < FPL; i++) C.sx[i] = C.sy[i] = C.sz[i] = 0;
@@ -376,6 +387,15 @@ int qc_set_kinematics(qc_handle* h, const qc_kinematics* kin) {
   return QC_OK;
 }
 
+int qc_set_gait(qc_handle* h, double t_swing, double t_stance) {
+  if (!h) return fail(QC_ERR_INVALID, "qc_set_gait: null handle");
+  if (!(t_swing >= 0.0) || !(t_stance >= 0.0) || !(t_swing + t_stance > 0.0)) return fail(QC_ERR_INVALID, "qc_set_gait: need t_swing, t_stance >= 0, not both 0");
+  h->dp.stance_phase = t_stance / (t_swing + t_stance);  // gait.cpp:45
+  QC_HIP(hipSetDevice(h->device));
+  QC_HIP(hipMemcpy(h->d_params, &h->dp, sizeof(qc::DevParams), hipMemcpyHostToDevice));
+  return QC_OK;
+}
+
 int qc_create(const qc_params* p, int device, qc_handle** out) {
   if (!p || !out) return fail(QC_ERR_INVALID, "qc_create: null argument");
   *out = nullptr;
@@ -449,6 +469,7 @@ int qc_create(const qc_params* p, int device, qc_handle** out) {
     d.tau_min = k.tau_min;
     d.tau_max = k.tau_max;
   }
+  d.stance_phase = 0.8 / (0.18 + 0.8);  // mit_cheetah_config.yaml:17-18
   d.tol_d = 1e-12;  // relative to 1+|grad|_inf: W ~ 1e-5 makes the primal very sensitive to a wrongly kept weakly-active face
   if (const char* e = std::getenv("QC_TOL_D")) d.tol_d = std::atof(e);  // development knob
   d.max_iter = p->max_iter > 0 ? p->max_iter : 200;
@@ -489,7 +510,8 @@ int qc_control_batch(qc_handle* h, size_t n, const qc_batch_in* in, const uint32
   if (out->joint_tau && !in->joint_q) return fail(QC_ERR_INVALID, "qc_control_batch: joint_tau needs joint_q");
   QC_HIP(hipSetDevice(h->device));
   const bool kin = in->joint_q != nullptr;
-  qc::BatchIn bi{in->Rwb, in->Rwb_d, in->x, in->xdot, in->w, in->x_d, in->xdot_d, in->w_d, in->feet, in->stance, in->joint_q};
+  qc::BatchIn bi{in->Rwb, in->Rwb_d, in->x, in->xdot, in->w, in->x_d, in->xdot_d, in->w_d, in->feet, in->stance, in->joint_q,
+                 in->gait_phase, in->gait_duty};
   qc::BatchOut bo{out->grf_body, out->status, out->active_set, out->iterations, out->joint_tau};
   // One wave per 64-thread block; a group of G lanes per robot.  The group
   // width trades latency for throughput: G = 4 (foot per lane) cuts the serial
@@ -541,7 +563,7 @@ int qc_control_batch_host(qc_handle* h, size_t n, const qc_batch_in* in, const u
   QC_HIP(hipSetDevice(h->device));
   if (!h->stream) QC_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   // layout (all 8-byte aligned): 48 doubles in, 12 doubles out, 4 x 4-byte words
-  const size_t per = 48 * 8 + 12 * 8 + 4 * 4 + 8 + 12 * 8 + 12 * 8;
+  const size_t per = 48 * 8 + 12 * 8 + 4 * 4 + 8 + 12 * 8 + 12 * 8 + 5 * 8;
   const size_t need = n * per + 256;
   if (need > h->stage_bytes) {
     if (h->stage) QC_HIP(hipFree(h->stage));
@@ -567,6 +589,15 @@ int qc_control_batch_host(qc_handle* h, size_t n, const qc_batch_in* in, const u
     QC_HIP(hipMemcpyAsync(d_q, in->joint_q, n * 12 * 8, hipMemcpyHostToDevice, h->stream));
   }
   double* d_tau = out->joint_tau ? (double*)carve(n * 12 * 8) : nullptr;
+  double *d_gp = nullptr, *d_gd = nullptr;
+  if (in->gait_phase) {
+    d_gp = (double*)carve(n * 4 * 8);
+    QC_HIP(hipMemcpyAsync(d_gp, in->gait_phase, n * 4 * 8, hipMemcpyHostToDevice, h->stream));
+  }
+  if (in->gait_duty) {
+    d_gd = (double*)carve(n * 8);
+    QC_HIP(hipMemcpyAsync(d_gd, in->gait_duty, n * 8, hipMemcpyHostToDevice, h->stream));
+  }
   uint8_t* d_st = nullptr;
   if (in->stance) {
     d_st = (uint8_t*)carve(n * 4);
@@ -582,7 +613,7 @@ int qc_control_batch_host(qc_handle* h, size_t n, const qc_batch_in* in, const u
   uint32_t* d_act = out->active_set ? (uint32_t*)carve(n * 4) : nullptr;
   int32_t* d_it = out->iterations ? (int32_t*)carve(n * 4) : nullptr;
   if (off > h->stage_bytes) return fail(QC_ERR_INVALID, "qc_control_batch_host: staging overflow");
-  qc_batch_in din{dptr[0], dptr[1], dptr[2], dptr[3], dptr[4], dptr[5], dptr[6], dptr[7], dptr[8], d_st, d_q};
+  qc_batch_in din{dptr[0], dptr[1], dptr[2], dptr[3], dptr[4], dptr[5], dptr[6], dptr[7], dptr[8], d_st, d_q, d_gp, d_gd};
   qc_batch_out dout{d_grf, d_status, d_act, d_it, d_tau};
   int rc = qc_control_batch(h, n, &din, d_warm, &dout, h->stream);
   if (rc != QC_OK) return rc;
@@ -598,7 +629,7 @@ int qc_control_batch_host(qc_handle* h, size_t n, const qc_batch_in* in, const u
 int qc_control(qc_handle* h, const double* Rwb, const double* Rwb_d, const double* x, const double* xdot,
                const double* w, const double* x_d, const double* xdot_d, const double* w_d, const double* feet,
                const uint8_t* stance, double* grf_body, int32_t* status) {
-  qc_batch_in in{Rwb, Rwb_d, x, xdot, w, x_d, xdot_d, w_d, feet, stance, nullptr};
+  qc_batch_in in{Rwb, Rwb_d, x, xdot, w, x_d, xdot_d, w_d, feet, stance, nullptr, nullptr, nullptr};
   qc_batch_out out{grf_body, status, nullptr, nullptr, nullptr};
   return qc_control_batch_host(h, 1, &in, nullptr, &out);
 }

@@ -45,6 +45,7 @@ struct DevParams {
   double hip[12];      // [leg][xyz] base -> hip
   double links[12];    // [leg][l1,l2,l3] signed
   double tau_min, tau_max;
+  double stance_phase; // gait.cpp:45, default duty of the on-device contact rule
   double tol_d;        // relative multiplier tolerance
   int max_iter;
   int pad;
@@ -67,6 +68,8 @@ struct BatchIn {
   const double *Rwb, *Rwb_d, *x, *xdot, *w, *x_d, *xdot_d, *w_d, *feet;
   const uint8_t* stance;
   const double* joint_q;
+  const double* gait_phase;
+  const double* gait_duty;
 };
 struct BatchOut {
   double* grf_body;

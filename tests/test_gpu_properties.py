@@ -248,3 +248,32 @@ def test_fused_tick_fk_and_torques(q, n):
     assert o3["joint_tau"].min() >= -5.0 and o3["joint_tau"].max() <= 7.0
     with pytest.raises(RuntimeError, match="joint_tau needs joint_q"):
         ctl.control_batch_host(b2, want_torques=True)
+
+
+def test_on_device_contact_rule(q):
+    """gait phases in, contact state derived on the device (gait.cpp:125-134) ==
+    the host-side rule used to build config 3 (quadruped_control_amd.gait)."""
+    from quadruped_control_amd import leg_state_from_phase
+    from quadruped_control_amd import workloads as W
+
+    rng = np.random.default_rng(21)
+    n = 5000
+    P = q.cheetah_params(0.6)
+    b = W.config2(n)
+    phases = rng.uniform(0.0, 1.0, (n, 4))
+    duty = np.where(rng.uniform(size=n) < 0.5, 0.5, 0.8 / 0.98)
+    phases[:50, 0] = 0.0                      # boundary cases of the 1e-12 slack
+    phases[50:100, 1] = duty[50:100]
+    phases[100:150, 2] = duty[100:150] + 5e-13
+    phases[150:200, 3] = duty[150:200] + 1e-9
+    stance = leg_state_from_phase(phases, duty[:, None])
+    ctl = q.BalanceController.from_params(P)
+    ref = ctl.control_batch_host(dict(b, stance=stance))
+    bg = {k: v for k, v in b.items() if k != "stance"}
+    out = ctl.control_batch_host(dict(bg, gait_phase=phases, gait_duty=duty))
+    assert np.array_equal(out["grf_body"], ref["grf_body"]) and np.array_equal(out["status"], ref["status"])
+    # handle-wide default duty (qc_set_gait)
+    ctl.set_gait(0.3, 0.3)
+    out2 = ctl.control_batch_host(dict(bg, gait_phase=phases))
+    ref2 = ctl.control_batch_host(dict(b, stance=leg_state_from_phase(phases, 0.5)))
+    assert np.array_equal(out2["grf_body"], ref2["grf_body"])

@@ -27,7 +27,7 @@ def test_param_struct_layout_matches_c():
     from quadruped_control_amd import _lib
 
     assert ctypes.sizeof(_lib.QcParams) == 8 * (4 + 9 + 36 + 144 + 6 + 3 * 4) + 8
-    assert ctypes.sizeof(_lib.QcBatchIn) == 11 * 8 and ctypes.sizeof(_lib.QcBatchOut) == 5 * 8
+    assert ctypes.sizeof(_lib.QcBatchIn) == 13 * 8 and ctypes.sizeof(_lib.QcBatchOut) == 5 * 8
     assert ctypes.sizeof(_lib.QcKinematics) == 26 * 8
 
 
