@@ -322,7 +322,9 @@ int oracle_qp_solve(const double* H, const double* g, const double* C, const dou
       int r = idx[t];
       lam[r] = rhs[NV + t];
       double viol = (ws[r] == 1) ? -lam[r] : (ws[r] == -1 ? lam[r] : 0.0);
-      if (viol > 1e-10 * gs && (bland ? (worst < 0 || idx[t] < idx[worst]) : viol > wv)) { wv = viol; worst = t; }
+      /* W ~ 1e-5 makes the primal very sensitive to a wrongly kept weakly-active row (a multiplier of
+       * -2e-7 moved a force by 3e-4 relative in testing), hence the tight relative threshold */
+      if (viol > 1e-13 * gs && (bland ? (worst < 0 || idx[t] < idx[worst]) : viol > wv)) { wv = viol; worst = t; }
     }
     if (worst < 0) {
       if (lam_out) memcpy(lam_out, lam, sizeof(lam));

@@ -277,3 +277,63 @@ def test_on_device_contact_rule(q):
     out2 = ctl.control_batch_host(dict(bg, gait_phase=phases))
     ref2 = ctl.control_batch_host(dict(b, stance=leg_state_from_phase(phases, 0.5)))
     assert np.array_equal(out2["grf_body"], ref2["grf_body"])
+
+
+def test_random_controller_parameters(q):
+    """Parity vs the oracle over randomly drawn constructor arguments (friction,
+    force limits, mass/inertia, gains, weights), incl. fzmin = fzmax and fzmin = 0."""
+    from oracle import c_oracle as O
+    from quadruped_control_amd import workloads as W
+
+    rng = np.random.default_rng(2024)
+    b = W.config3(768)
+    worst = 0.0
+    for trial in range(12):
+        P = q.cheetah_params(float(rng.uniform(0.2, 1.2)))
+        P["fzmin"] = float(rng.choice([0.0, 5.0, 10.0, 25.0]))
+        P["fzmax"] = P["fzmin"] if trial == 3 else float(P["fzmin"] + rng.uniform(20.0, 200.0))
+        P["mass"] = float(rng.uniform(5.0, 30.0))
+        P["Ib"] = np.diag(rng.uniform(0.01, 0.2, 3))
+        P["S"] = np.diag(rng.uniform(0.5, 20.0, 6))
+        P["W"] = np.eye(12) * float(10.0 ** rng.uniform(-6, -3))
+        P["kp_w"] = np.full(3, float(rng.uniform(100.0, 5000.0)))
+        P["kd_w"] = np.full(3, float(rng.uniform(10.0, 500.0)))
+        P["kff"] = rng.uniform(0.0, 0.3, 6)
+        if trial % 4 == 1:   # per-axis W -> general 6x6 form
+            P["W"] = np.diag(10.0 ** rng.uniform(-6, -3, 12))
+        if trial % 4 == 2:   # full SPD S -> general 6x6 form
+            A = rng.normal(size=(6, 6)); P["S"] = P["S"] + 0.2 * A @ A.T
+        ctl = q.BalanceController.from_params(P)
+        o = ctl.control_batch_host(b)
+        ref, st, _ = O.control_batch(P, b, threads=8)
+        assert (o["status"] == 0).all() and (st == 0).all(), (trial, ctl.kernel_name)
+        scale = np.maximum(1.0, np.abs(ref).max(axis=1, keepdims=True))
+        err = float(np.max(np.abs(o["grf_body"] - ref) / scale))
+        worst = max(worst, err)
+        assert err < 1e-6, (trial, ctl.kernel_name, err)
+
+
+def test_graph_capture_replay(q):
+    """qc_control_batch is a pure kernel launch on the given stream: it can be
+    captured into a HIP graph and replayed (launch-bound small batches)."""
+    import torch
+
+    from quadruped_control_amd import workloads as W
+
+    P = q.cheetah_params(0.6)
+    ctl = q.BalanceController.from_params(P)
+    d = q.to_device(W.config2(4096))
+    launch, out = ctl.plan_batch(d)
+    torch.cuda.synchronize()
+    ref = out["grf_body"].clone()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        launch_s, out_s = ctl.plan_batch(d, stream=s)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=s):
+            launch_s()
+    out_s["grf_body"].zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out_s["grf_body"], ref)
