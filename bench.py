@@ -192,8 +192,15 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # QC_BENCH_ONE_DEVICE=1 (test hook): all ranks share cuda:0 and talk over gloo, so the
+        # multi-process path can be exercised on a 1-GPU box; the real run is one rank per GPU over RCCL.
+        one_dev = os.environ.get("QC_BENCH_ONE_DEVICE") == "1"
+        if one_dev:
+            local_rank = 0
+            dist_mod.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         dist = dist_mod
     device = local_rank if world > 1 else 0
     torch.cuda.set_device(device)
@@ -206,8 +213,9 @@ def main():
 
     from quadruped_control_amd.sharding import reduce_counters
 
+    on_gpu = dist is not None and dist.get_backend() == "nccl"
     wall, solved_total, total_robots = reduce_counters(dist, res["wall"], res["solved"], n,
-                                                       device=f"cuda:{device}" if dist is not None else None)
+                                                       device=f"cuda:{device}" if on_gpu else None)
 
     if rank == 0:
         bytes_per = BYTES_PER_ROBOT_WARM if res["warm"] else BYTES_PER_ROBOT_COLD
