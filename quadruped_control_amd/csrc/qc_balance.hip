@@ -35,6 +35,11 @@ namespace qc {
 // park their result and, once `refill_t` groups are parked, the wave flushes
 // their outputs and hands them the next robots of the chunk.  This keeps the
 // lanes busy although robots need between 1 and ~20 recalculations.
+// LDS stock planes (see the dense phases below)
+enum { IN_B = 0, IN_R = 6, IN_FLAGS = 18, IN_IDX = 19, IN_PLANES = 20,
+       OUT_F = 0, OUT_STAT = 12, OUT_WORD = 13, OUT_IDX = 14, OUT_PLANES = 15,
+       STOCK_PLANES = IN_PLANES + OUT_PLANES };
+
 template <class Eqp, bool KIN>
 struct Lane {
   static constexpr int G = Eqp::G;
@@ -152,142 +157,242 @@ struct Lane {
     return iters >= P.max_iter;  // status stays QC_MAX_ITER
   }
 
-  // fetch robot `robot` into this lane's group
-  QC_DEV void load(CParams& P, const BatchIn& in, const uint32_t* __restrict__ warm, long robot, int member) {
-    idx = robot;
+  // take the robot staged in `slot` of the wave's input stock into this lane's group
+  QC_DEV void load_from_stock(const double* __restrict__ sin, int slot, int member) {
     foot0 = member * FPL;
-    const double fin = build_wrench<FPL, KIN>(P, in, robot, foot0, Wr);
-    stance = 0xFu;  // make_stance_gait(), gait.cpp:24-34
-    if (in.stance) {
-      const uint32_t sw = *reinterpret_cast<const uint32_t*>(in.stance + 4 * robot);
-      stance = ((sw & 0xFFu) ? 1u : 0u) | ((sw & 0xFF00u) ? 2u : 0u) | ((sw & 0xFF0000u) ? 4u : 0u) | ((sw & 0xFF000000u) ? 8u : 0u);
-    } else if (in.gait_phase) {
-      // GaitScheduler::phase(), gait.cpp:125-134 (almost_equal = |a-b| < 1e-12, math/numerics.cpp:18-21)
-      const double duty = in.gait_duty ? in.gait_duty[robot] : P.stance_phase;
-      stance = 0;
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const double ph = in.gait_phase[4 * robot + i];
-        const bool ge0 = (ph > 0.0) || (fabs(ph) < 1.0e-12);
-        const bool le = (ph < duty) || (fabs(ph - duty) < 1.0e-12);
-        stance |= (ge0 && le) ? (1u << i) : 0u;
-      }
-    }
+    for (int k = 0; k < 6; k++) Wr.b[k] = sin[(IN_B + k) * 64 + slot];
 #pragma unroll
-    for (int i = 0; i < FPL; i++) C.sx[i] = C.sy[i] = C.sz[i] = 0;
-    if (warm) {
-      const uint32_t wv = warm[robot];
-      if (wv & 0x80000000u) {
+    for (int i = 0; i < FPL; i++)
 #pragma unroll
-        for (int i = 0; i < FPL; i++) {
-          const uint32_t fb = wv >> (6 * (foot0 + i));
-          const bool st = (stance >> (foot0 + i)) & 1u;
-          C.sx[i] = st ? dec2(fb) : 0;
-          C.sy[i] = st ? dec2(fb >> 2) : 0;
-          C.sz[i] = st ? dec2(fb >> 4) : 0;
-        }
-      }
+      for (int k = 0; k < 3; k++) Wr.r[i][k] = sin[(IN_R + 3 * (foot0 + i) + k) * 64 + slot];
+    const unsigned long long fl = (unsigned long long)__double_as_longlong(sin[IN_FLAGS * 64 + slot]);
+    stance = (uint32_t)fl;
+    const uint32_t wv = (uint32_t)(fl >> 32);
+    idx = __double_as_longlong(sin[IN_IDX * 64 + slot]);
+    const bool use_warm = (wv & 0x80000000u) != 0;
+#pragma unroll
+    for (int i = 0; i < FPL; i++) {
+      const uint32_t fb = wv >> (6 * (foot0 + i));
+      const bool st = use_warm && ((stance >> (foot0 + i)) & 1u);
+      C.sx[i] = st ? dec2(fb) : 0;
+      C.sy[i] = st ? dec2(fb >> 2) : 0;
+      C.sz[i] = st ? dec2(fb >> 4) : 0;
     }
 #pragma unroll
     for (int k = 0; k < 3 * FPL; k++) f[k] = 0.0;
     status = QC_MAX_ITER;
     iters = 0;
     have_f = false;
-    // non-finite inputs poison b, r or R: report QC_NOT_PD instead of iterating on NaNs
-    const int bad = group_or<G>(!(fin == 0.0) ? 1 : 0);
-    if (bad) {
-#pragma unroll
-      for (int k = 0; k < 6; k++) Wr.b[k] = 0.0;
-#pragma unroll
-      for (int i = 0; i < FPL; i++) Wr.r[i][0] = Wr.r[i][1] = Wr.r[i][2] = 0.0;
-      stance |= 0x100u;
-    }
   }
 
-  // output transform, BC.cpp:218-232: fb = -Rwb^T fw for stance legs (Rwb re-read: cheaper than 18 live VGPRs)
-  QC_DEV void store(CParams& P, const BatchIn& in, const BatchOut& out) const {
-    const double* Rp = in.Rwb + 9 * idx;
-    double R[9];
-#pragma unroll
-    for (int k = 0; k < 9; k++) R[k] = Rp[k];
-    const int st_out = (stance & 0x100u) ? (int)QC_NOT_PD : status;
-    double* o = out.grf_body + 12 * idx + 3 * foot0;
+  // park the finished robot's result in `slot` of the wave's output stock
+  QC_DEV void push_result(double* __restrict__ sout, int slot) const {
     uint32_t word = 0;
 #pragma unroll
     for (int i = 0; i < FPL; i++) {
-      const bool st = ((stance >> (foot0 + i)) & 1u) && st_out == QC_SOLVED;
-      double fb[3];
 #pragma unroll
-      for (int r = 0; r < 3; r++) {
-        const double v = -(R[r] * f[3 * i] + R[3 + r] * f[3 * i + 1] + R[6 + r] * f[3 * i + 2]);
-        fb[r] = st ? v : 0.0;
-        o[3 * i + r] = fb[r];
-      }
-      if (KIN && out.joint_tau) {  // commander_node.cpp:511-526: tau = clamp(J^T f, tau_min, tau_max)
-        double tau[3];
-        leg_jt_force(P, foot0 + i, leg_trig(in.joint_q + 12 * idx + 3 * (foot0 + i)), fb, tau);
-        double* to = out.joint_tau + 12 * idx + 3 * (foot0 + i);
-#pragma unroll
-        for (int r = 0; r < 3; r++) to[r] = st ? fmin(fmax(tau[r], P.tau_min), P.tau_max) : 0.0;
-      }
+      for (int k = 0; k < 3; k++) sout[(OUT_F + 3 * (foot0 + i) + k) * 64 + slot] = f[3 * i + k];
       word |= encode_foot(C.sx[i], C.sy[i], C.sz[i]) << (6 * (foot0 + i));
     }
     word = (uint32_t)group_or<G>((int)word) | 0x80000000u;
     if (foot0 == 0) {
-      out.status[idx] = st_out;
-      if (out.active_set) out.active_set[idx] = word;
-      if (out.iterations) out.iterations[idx] = iters;
+      sout[OUT_STAT * 64 + slot] = __longlong_as_double((long long)(((unsigned long long)(uint32_t)iters << 32) | (uint32_t)status));
+      sout[OUT_WORD * 64 + slot] = __longlong_as_double((long long)(((unsigned long long)stance << 32) | word));
+      sout[OUT_IDX * 64 + slot] = __longlong_as_double(idx);
     }
   }
 };
+
+// Dense phases around the divergent solve.  Robots need 1 ... ~20
+// recalculations, so the solver lanes are refilled a few at a time; running the
+// expensive per-robot assembly (rotation log with atan2/sqrt, Newton-Euler
+// right-hand side, optional forward kinematics: ~1400 instructions) and the
+// output transform under such sparse exec masks would waste most of the wave.
+// Instead every LANE assembles one whole robot for a stock of 64 robots in LDS,
+// groups pull from the stock with a handful of ds_reads, finished groups push
+// their world-frame forces to an output stock, and a dense pass (again one robot
+// per lane) rotates them to the body frame, applies J^T and stores.
+// Stock planes are [field][64 slots] doubles: the dense side touches
+// plane[field][lane] (conflict-free), the group side one slot per group.
+// FPL = 4: one lane assembles a whole robot (dense restock of a big batch);
+// FPL = 4/G: the G lanes of a group share a robot, each doing its own feet
+// (small fills, where latency matters more than lane efficiency).
+template <bool KIN, int FPL>
+QC_DEV void assemble_to_stock(CParams& P, const BatchIn& in, const uint32_t* __restrict__ warm, long robot, int slot, int member,
+                              double* __restrict__ sin) {
+  constexpr int GG = 4 / FPL;
+  Wrench<FPL> W;
+  const int foot0 = member * FPL;
+  const double fin = build_wrench<FPL, KIN>(P, in, robot, foot0, W);
+  uint32_t stance = 0xFu;  // make_stance_gait(), gait.cpp:24-34
+  if (in.stance) {
+    const uint32_t sw = *reinterpret_cast<const uint32_t*>(in.stance + 4 * robot);
+    stance = ((sw & 0xFFu) ? 1u : 0u) | ((sw & 0xFF00u) ? 2u : 0u) | ((sw & 0xFF0000u) ? 4u : 0u) | ((sw & 0xFF000000u) ? 8u : 0u);
+  } else if (in.gait_phase) {
+    // GaitScheduler::phase(), gait.cpp:125-134 (almost_equal = |a-b| < 1e-12, math/numerics.cpp:18-21)
+    const double duty = in.gait_duty ? in.gait_duty[robot] : P.stance_phase;
+    stance = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const double ph = in.gait_phase[4 * robot + i];
+      const bool ge0 = (ph > 0.0) || (fabs(ph) < 1.0e-12);
+      const bool le = (ph < duty) || (fabs(ph - duty) < 1.0e-12);
+      stance |= (ge0 && le) ? (1u << i) : 0u;
+    }
+  }
+  const uint32_t wv = warm ? warm[robot] : 0u;
+  // non-finite inputs poison b, r or R: report QC_NOT_PD instead of iterating on NaNs
+  const bool bad = group_or<GG>(!(fin == 0.0) ? 1 : 0) != 0;
+  if (bad) stance |= 0x100u;
+#pragma unroll
+  for (int i = 0; i < FPL; i++)
+#pragma unroll
+    for (int k = 0; k < 3; k++) sin[(IN_R + 3 * (foot0 + i) + k) * 64 + slot] = bad ? 0.0 : W.r[i][k];
+  if (member == 0) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) sin[(IN_B + k) * 64 + slot] = bad ? 0.0 : W.b[k];
+    sin[IN_FLAGS * 64 + slot] = __longlong_as_double((long long)(((unsigned long long)wv << 32) | stance));
+    sin[IN_IDX * 64 + slot] = __longlong_as_double(robot);
+  }
+}
+
+// output transform, BC.cpp:218-232: fb = -Rwb^T fw for stance legs; optional torque map
+template <bool KIN, int FPL>
+QC_DEV void store_from_stock(CParams& P, const BatchIn& in, const BatchOut& out, const double* __restrict__ sout, int slot, int member) {
+  const int foot0 = member * FPL;
+  const long idx = __double_as_longlong(sout[OUT_IDX * 64 + slot]);
+  const unsigned long long sw = (unsigned long long)__double_as_longlong(sout[OUT_STAT * 64 + slot]);
+  const unsigned long long ww = (unsigned long long)__double_as_longlong(sout[OUT_WORD * 64 + slot]);
+  const int status = (int)(uint32_t)sw, iters = (int)(uint32_t)(sw >> 32);
+  const uint32_t word = (uint32_t)ww, stance = (uint32_t)(ww >> 32);
+  const double* Rp = in.Rwb + 9 * idx;
+  double R[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) R[k] = Rp[k];
+  const int st_out = (stance & 0x100u) ? (int)QC_NOT_PD : status;
+  double* o = out.grf_body + 12 * idx + 3 * foot0;
+#pragma unroll
+  for (int i = 0; i < FPL; i++) {
+    const bool st = ((stance >> (foot0 + i)) & 1u) && st_out == QC_SOLVED;
+    double f[3], fb[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) f[k] = sout[(OUT_F + 3 * (foot0 + i) + k) * 64 + slot];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      const double v = -(R[r] * f[0] + R[3 + r] * f[1] + R[6 + r] * f[2]);
+      fb[r] = st ? v : 0.0;
+      o[3 * i + r] = fb[r];
+    }
+    if (KIN && out.joint_tau) {  // commander_node.cpp:511-526: tau = clamp(J^T f, tau_min, tau_max)
+      double tau[3];
+      leg_jt_force(P, foot0 + i, leg_trig(in.joint_q + 12 * idx + 3 * (foot0 + i)), fb, tau);
+      double* to = out.joint_tau + 12 * idx + 3 * (foot0 + i);
+#pragma unroll
+      for (int r = 0; r < 3; r++) to[r] = st ? fmin(fmax(tau[r], P.tau_min), P.tau_max) : 0.0;
+    }
+  }
+  if (member == 0) {
+    out.status[idx] = st_out;
+    if (out.active_set) out.active_set[idx] = word;
+    if (out.iterations) out.iterations[idx] = iters;
+  }
+}
+
+// store the robots parked in the output stock: one per lane, or one per lane group when there are few
+template <int G, bool KIN>
+QC_DEV void flush_out(const DevParams* __restrict__ Pg, const BatchIn& in, const BatchOut& out, const double* __restrict__ sout, int out_n, int lane) {
+  if (G > 1 && out_n <= 64 / G) {
+    if (lane / G < out_n) {
+      CParams& P = *QC_PARAMS_HERE(Pg);
+      store_from_stock<KIN, 4 / G>(P, in, out, sout, lane / G, lane & (G - 1));
+    }
+  } else if (lane < out_n) {
+    CParams& P = *QC_PARAMS_HERE(Pg);
+    store_from_stock<KIN, 4>(P, in, out, sout, lane, 0);
+  }
+}
 
 template <class Eqp, bool KIN, int MIN_WAVES_PER_SIMD>
 __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const DevParams* __restrict__ Pg, const long n, const BatchIn in,
                                                                          const uint32_t* __restrict__ warm, const BatchOut out, const long chunk,
                                                                          const int refill_t) {
   constexpr int G = Eqp::G;
-  extern __shared__ __attribute__((aligned(16))) double qc_lds[];  // dense path: 78 planes x 64 lanes; unused (size 0) otherwise
-  long cursor = (long)blockIdx.x * chunk;  // wave-uniform
+  extern __shared__ __attribute__((aligned(16))) double qc_lds[];  // [stock planes][64] (+ the dense form's 78 Hessian planes)
+  double* const sin = qc_lds;
+  double* const sout = qc_lds + IN_PLANES * 64;
+  long cursor = (long)blockIdx.x * chunk;  // wave-uniform: next robot of this wave's chunk to assemble
   const long end = cursor + chunk < n ? cursor + chunk : n;
-  const int member = threadIdx.x & (G - 1);
+  const int lane = threadIdx.x;
+  const int member = lane & (G - 1);
+  int stock_n = 0, stock_next = 0;  // input stock: slots [stock_next, stock_n) hold assembled robots
+  int out_n = 0;                    // output stock: slots [0, out_n) hold finished results
   Lane<Eqp, KIN> L;
   L.idx = -1;
   L.foot0 = member * (4 / G);
-  Eqp eqp(qc_lds + threadIdx.x);
-  bool busy = false;     // group holds an unfinished robot
-  bool parked = false;   // group holds a finished robot whose outputs are not stored yet
+  Eqp eqp(qc_lds + STOCK_PLANES * 64 + lane);
+  bool busy = false;  // group holds an unfinished robot
   for (;;) {
     const unsigned long long busy_mask = __builtin_amdgcn_ballot_w64(busy);
     const int n_free = (64 - __builtin_popcountll(busy_mask)) / G;  // free groups
-    const long remaining = end - cursor;
-    const bool refill = remaining > 0 && (n_free >= refill_t || busy_mask == 0);
-    if (refill || busy_mask == 0) {
-      if (parked) {
-        CParams& P = *QC_PARAMS_HERE(Pg);
-        L.store(P, in, out);
-        parked = false;
+    const long avail = (end - cursor) + (long)(stock_n - stock_next);
+    if (avail > 0 && (n_free >= refill_t || busy_mask == 0)) {
+      if (stock_next == stock_n) {  // restock: dense assembly, one robot per lane
+        const long left = end - cursor;
+        const int k = left < 64 ? (int)left : 64;
+        if (G > 1 && k <= 64 / G) {  // few robots: the lanes of a group share one
+          if (lane / G < k) {
+            CParams& P = *QC_PARAMS_HERE(Pg);
+            assemble_to_stock<KIN, 4 / G>(P, in, warm, cursor + lane / G, lane / G, member, sin);
+          }
+        } else if (lane < k) {
+          CParams& P = *QC_PARAMS_HERE(Pg);
+          assemble_to_stock<KIN, 4>(P, in, warm, cursor + lane, lane, 0, sin);
+        }
+        __syncthreads();
+        stock_n = k;
+        stock_next = 0;
+        cursor += k;
       }
-    }
-    if (refill) {
+      const int have = stock_n - stock_next;
+      const int take = n_free < have ? n_free : have;
       const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(~busy_mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)~busy_mask, 0)) / G;
-      if (!busy && rank < remaining) {
+      if (!busy && rank < take) {
+        L.load_from_stock(sin, stock_next + rank, member);
         CParams& P = *QC_PARAMS_HERE(Pg);
-        L.load(P, in, warm, cursor + rank, member);
         eqp.setup(P, L.Wr);
         busy = true;
       }
-      cursor += n_free < remaining ? n_free : remaining;
+      stock_next += take;
       continue;
     }
     if (busy_mask == 0) break;
+    bool fin = false;
     if (busy) {
       asm volatile("; QC_ITER_BEGIN");
       CParams& P = *QC_PARAMS_HERE(Pg);
-      const bool fin = L.iterate(P, eqp);
+      fin = L.iterate(P, eqp);
       asm volatile("; QC_ITER_END");
-      if (fin) { busy = false; parked = true; }
+    }
+    const unsigned long long fin_mask = __builtin_amdgcn_ballot_w64(fin);
+    if (fin_mask != 0) {
+      const int n_fin = __builtin_popcountll(fin_mask) / G;
+      if (out_n + n_fin > 64) {  // dense flush of the output stock, one robot per lane
+        __syncthreads();
+        flush_out<Eqp::G, KIN>(Pg, in, out, sout, out_n, lane);
+        __syncthreads();
+        out_n = 0;
+      }
+      if (fin) {
+        const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(fin_mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fin_mask, 0)) / G;
+        L.push_result(sout, out_n + rank);
+        busy = false;
+      }
+      out_n += n_fin;
     }
   }
+  __syncthreads();
+  flush_out<Eqp::G, KIN>(Pg, in, out, sout, out_n, lane);
 }
 
 }  // namespace qc
@@ -542,11 +647,12 @@ int qc_control_batch(qc_handle* h, size_t n, const qc_batch_in* in, const uint32
     if (kin) qc::balance_kernel<EQP, true, MINW><<<dim3(blocks), dim3(64), LDS, st>>>(h->d_params, (long)n, bi, warm, bo, chunk, refill_t);  \
     else qc::balance_kernel<EQP, false, MINW><<<dim3(blocks), dim3(64), LDS, st>>>(h->d_params, (long)n, bi, warm, bo, chunk, refill_t);     \
   } while (0)
-  if (!h->diag_w) QC_LAUNCH(qc::EqpDense, 1, 78 * 64 * sizeof(double));
-  else if (!h->uniform) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<false, 1>), 2, 0);
-  else if (G == 4) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<true, 4>), 2, 0);
-  else if (G == 2) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<true, 2>), 2, 0);
-  else QC_LAUNCH(QC_COMMA(qc::EqpDiagW<true, 1>), 2, 0);
+  constexpr size_t kStock = qc::STOCK_PLANES * 64 * sizeof(double);
+  if (!h->diag_w) QC_LAUNCH(qc::EqpDense, 1, kStock + 78 * 64 * sizeof(double));
+  else if (!h->uniform) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<false, 1>), 2, kStock);
+  else if (G == 4) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<true, 4>), 2, kStock);
+  else if (G == 2) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<true, 2>), 2, kStock);
+  else QC_LAUNCH(QC_COMMA(qc::EqpDiagW<true, 1>), 2, kStock);
 #undef QC_LAUNCH
   QC_HIP(hipGetLastError());
   return QC_OK;
