@@ -36,9 +36,12 @@ namespace qc {
 // their outputs and hands them the next robots of the chunk.  This keeps the
 // lanes busy although robots need between 1 and ~20 recalculations.
 // LDS stock planes (see the dense phases below)
+// SP = plane stride in doubles: 65, not 64, so that the lanes of one group (same
+// slot, planes 3*FPL apart) fall into different banks; the dense side
+// (plane[f][lane]) is conflict-free either way.
 enum { IN_B = 0, IN_R = 6, IN_FLAGS = 18, IN_IDX = 19, IN_PLANES = 20,
        OUT_F = 0, OUT_STAT = 12, OUT_WORD = 13, OUT_IDX = 14, OUT_PLANES = 15,
-       STOCK_PLANES = IN_PLANES + OUT_PLANES };
+       STOCK_PLANES = IN_PLANES + OUT_PLANES, SP = 65, STOCK_DOUBLES = ((STOCK_PLANES * SP + 63) / 64) * 64 };
 
 template <class Eqp, bool KIN>
 struct Lane {
@@ -161,15 +164,15 @@ struct Lane {
   QC_DEV void load_from_stock(const double* __restrict__ sin, int slot, int member) {
     foot0 = member * FPL;
 #pragma unroll
-    for (int k = 0; k < 6; k++) Wr.b[k] = sin[(IN_B + k) * 64 + slot];
+    for (int k = 0; k < 6; k++) Wr.b[k] = sin[(IN_B + k) * SP + slot];
 #pragma unroll
     for (int i = 0; i < FPL; i++)
 #pragma unroll
-      for (int k = 0; k < 3; k++) Wr.r[i][k] = sin[(IN_R + 3 * (foot0 + i) + k) * 64 + slot];
-    const unsigned long long fl = (unsigned long long)__double_as_longlong(sin[IN_FLAGS * 64 + slot]);
+      for (int k = 0; k < 3; k++) Wr.r[i][k] = sin[(IN_R + 3 * (foot0 + i) + k) * SP + slot];
+    const unsigned long long fl = (unsigned long long)__double_as_longlong(sin[IN_FLAGS * SP + slot]);
     stance = (uint32_t)fl;
     const uint32_t wv = (uint32_t)(fl >> 32);
-    idx = __double_as_longlong(sin[IN_IDX * 64 + slot]);
+    idx = __double_as_longlong(sin[IN_IDX * SP + slot]);
     const bool use_warm = (wv & 0x80000000u) != 0;
 #pragma unroll
     for (int i = 0; i < FPL; i++) {
@@ -192,14 +195,14 @@ struct Lane {
 #pragma unroll
     for (int i = 0; i < FPL; i++) {
 #pragma unroll
-      for (int k = 0; k < 3; k++) sout[(OUT_F + 3 * (foot0 + i) + k) * 64 + slot] = f[3 * i + k];
+      for (int k = 0; k < 3; k++) sout[(OUT_F + 3 * (foot0 + i) + k) * SP + slot] = f[3 * i + k];
       word |= encode_foot(C.sx[i], C.sy[i], C.sz[i]) << (6 * (foot0 + i));
     }
     word = (uint32_t)group_or<G>((int)word) | 0x80000000u;
     if (foot0 == 0) {
-      sout[OUT_STAT * 64 + slot] = __longlong_as_double((long long)(((unsigned long long)(uint32_t)iters << 32) | (uint32_t)status));
-      sout[OUT_WORD * 64 + slot] = __longlong_as_double((long long)(((unsigned long long)stance << 32) | word));
-      sout[OUT_IDX * 64 + slot] = __longlong_as_double(idx);
+      sout[OUT_STAT * SP + slot] = __longlong_as_double((long long)(((unsigned long long)(uint32_t)iters << 32) | (uint32_t)status));
+      sout[OUT_WORD * SP + slot] = __longlong_as_double((long long)(((unsigned long long)stance << 32) | word));
+      sout[OUT_IDX * SP + slot] = __longlong_as_double(idx);
     }
   }
 };
@@ -248,12 +251,12 @@ QC_DEV void assemble_to_stock(CParams& P, const BatchIn& in, const uint32_t* __r
 #pragma unroll
   for (int i = 0; i < FPL; i++)
 #pragma unroll
-    for (int k = 0; k < 3; k++) sin[(IN_R + 3 * (foot0 + i) + k) * 64 + slot] = bad ? 0.0 : W.r[i][k];
+    for (int k = 0; k < 3; k++) sin[(IN_R + 3 * (foot0 + i) + k) * SP + slot] = bad ? 0.0 : W.r[i][k];
   if (member == 0) {
 #pragma unroll
-    for (int k = 0; k < 6; k++) sin[(IN_B + k) * 64 + slot] = bad ? 0.0 : W.b[k];
-    sin[IN_FLAGS * 64 + slot] = __longlong_as_double((long long)(((unsigned long long)wv << 32) | stance));
-    sin[IN_IDX * 64 + slot] = __longlong_as_double(robot);
+    for (int k = 0; k < 6; k++) sin[(IN_B + k) * SP + slot] = bad ? 0.0 : W.b[k];
+    sin[IN_FLAGS * SP + slot] = __longlong_as_double((long long)(((unsigned long long)wv << 32) | stance));
+    sin[IN_IDX * SP + slot] = __longlong_as_double(robot);
   }
 }
 
@@ -261,9 +264,9 @@ QC_DEV void assemble_to_stock(CParams& P, const BatchIn& in, const uint32_t* __r
 template <bool KIN, int FPL>
 QC_DEV void store_from_stock(CParams& P, const BatchIn& in, const BatchOut& out, const double* __restrict__ sout, int slot, int member) {
   const int foot0 = member * FPL;
-  const long idx = __double_as_longlong(sout[OUT_IDX * 64 + slot]);
-  const unsigned long long sw = (unsigned long long)__double_as_longlong(sout[OUT_STAT * 64 + slot]);
-  const unsigned long long ww = (unsigned long long)__double_as_longlong(sout[OUT_WORD * 64 + slot]);
+  const long idx = __double_as_longlong(sout[OUT_IDX * SP + slot]);
+  const unsigned long long sw = (unsigned long long)__double_as_longlong(sout[OUT_STAT * SP + slot]);
+  const unsigned long long ww = (unsigned long long)__double_as_longlong(sout[OUT_WORD * SP + slot]);
   const int status = (int)(uint32_t)sw, iters = (int)(uint32_t)(sw >> 32);
   const uint32_t word = (uint32_t)ww, stance = (uint32_t)(ww >> 32);
   const double* Rp = in.Rwb + 9 * idx;
@@ -277,7 +280,7 @@ QC_DEV void store_from_stock(CParams& P, const BatchIn& in, const BatchOut& out,
     const bool st = ((stance >> (foot0 + i)) & 1u) && st_out == QC_SOLVED;
     double f[3], fb[3];
 #pragma unroll
-    for (int k = 0; k < 3; k++) f[k] = sout[(OUT_F + 3 * (foot0 + i) + k) * 64 + slot];
+    for (int k = 0; k < 3; k++) f[k] = sout[(OUT_F + 3 * (foot0 + i) + k) * SP + slot];
 #pragma unroll
     for (int r = 0; r < 3; r++) {
       const double v = -(R[r] * f[0] + R[3 + r] * f[1] + R[6 + r] * f[2]);
@@ -320,7 +323,7 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
   constexpr int G = Eqp::G;
   extern __shared__ __attribute__((aligned(16))) double qc_lds[];  // [stock planes][64] (+ the dense form's 78 Hessian planes)
   double* const sin = qc_lds;
-  double* const sout = qc_lds + IN_PLANES * 64;
+  double* const sout = qc_lds + IN_PLANES * SP;
   long cursor = (long)blockIdx.x * chunk;  // wave-uniform: next robot of this wave's chunk to assemble
   const long end = cursor + chunk < n ? cursor + chunk : n;
   const int lane = threadIdx.x;
@@ -330,7 +333,7 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
   Lane<Eqp, KIN> L;
   L.idx = -1;
   L.foot0 = member * (4 / G);
-  Eqp eqp(qc_lds + STOCK_PLANES * 64 + lane);
+  Eqp eqp(qc_lds + STOCK_DOUBLES + lane);
   bool busy = false;  // group holds an unfinished robot
   for (;;) {
     const unsigned long long busy_mask = __builtin_amdgcn_ballot_w64(busy);
@@ -647,7 +650,7 @@ int qc_control_batch(qc_handle* h, size_t n, const qc_batch_in* in, const uint32
     if (kin) qc::balance_kernel<EQP, true, MINW><<<dim3(blocks), dim3(64), LDS, st>>>(h->d_params, (long)n, bi, warm, bo, chunk, refill_t);  \
     else qc::balance_kernel<EQP, false, MINW><<<dim3(blocks), dim3(64), LDS, st>>>(h->d_params, (long)n, bi, warm, bo, chunk, refill_t);     \
   } while (0)
-  constexpr size_t kStock = qc::STOCK_PLANES * 64 * sizeof(double);
+  constexpr size_t kStock = qc::STOCK_DOUBLES * sizeof(double);
   if (!h->diag_w) QC_LAUNCH(qc::EqpDense, 1, kStock + 78 * 64 * sizeof(double));
   else if (!h->uniform) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<false, 1>), 2, kStock);
   else if (G == 4) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<true, 4>), 2, kStock);
