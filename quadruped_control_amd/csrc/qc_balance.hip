@@ -302,6 +302,25 @@ QC_DEV void store_from_stock(CParams& P, const BatchIn& in, const BatchOut& out,
   }
 }
 
+// dense assembly of the next (up to 64) robots of the chunk into the input stock; returns how many
+template <int G, bool KIN>
+QC_DEV int restock(const DevParams* __restrict__ Pg, const BatchIn& in, const uint32_t* __restrict__ warm, long cursor, long end, int lane,
+                   int member, double* __restrict__ sin) {
+  const long left = end - cursor;
+  const int k = left < 64 ? (int)left : 64;
+  if (G > 1 && k <= 64 / G) {  // few robots: the lanes of a group share one
+    if (lane / G < k) {
+      CParams& P = *QC_PARAMS_HERE(Pg);
+      assemble_to_stock<KIN, 4 / G>(P, in, warm, cursor + lane / G, lane / G, member, sin);
+    }
+  } else if (lane < k) {
+    CParams& P = *QC_PARAMS_HERE(Pg);
+    assemble_to_stock<KIN, 4>(P, in, warm, cursor + lane, lane, 0, sin);
+  }
+  __syncthreads();
+  return k;
+}
+
 // store the robots parked in the output stock: one per lane, or one per lane group when there are few
 template <int G, bool KIN>
 QC_DEV void flush_out(const DevParams* __restrict__ Pg, const BatchIn& in, const BatchOut& out, const double* __restrict__ sout, int out_n, int lane) {
@@ -335,27 +354,22 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
   L.foot0 = member * (4 / G);
   Eqp eqp(qc_lds + STOCK_DOUBLES + lane);
   bool busy = false;  // group holds an unfinished robot
+  // The first restock runs before any solver state is live, so (unlike its copy
+  // inside the loop) it needs no spills: batches that fit one fill per wave
+  // never execute the in-loop copy.
+  if (cursor < end) {
+    stock_n = restock<G, KIN>(Pg, in, warm, cursor, end, lane, member, sin);
+    cursor += stock_n;
+  }
   for (;;) {
     const unsigned long long busy_mask = __builtin_amdgcn_ballot_w64(busy);
     const int n_free = (64 - __builtin_popcountll(busy_mask)) / G;  // free groups
     const long avail = (end - cursor) + (long)(stock_n - stock_next);
     if (avail > 0 && (n_free >= refill_t || busy_mask == 0)) {
-      if (stock_next == stock_n) {  // restock: dense assembly, one robot per lane
-        const long left = end - cursor;
-        const int k = left < 64 ? (int)left : 64;
-        if (G > 1 && k <= 64 / G) {  // few robots: the lanes of a group share one
-          if (lane / G < k) {
-            CParams& P = *QC_PARAMS_HERE(Pg);
-            assemble_to_stock<KIN, 4 / G>(P, in, warm, cursor + lane / G, lane / G, member, sin);
-          }
-        } else if (lane < k) {
-          CParams& P = *QC_PARAMS_HERE(Pg);
-          assemble_to_stock<KIN, 4>(P, in, warm, cursor + lane, lane, 0, sin);
-        }
-        __syncthreads();
-        stock_n = k;
+      if (stock_next == stock_n) {
+        stock_n = restock<G, KIN>(Pg, in, warm, cursor, end, lane, member, sin);
         stock_next = 0;
-        cursor += k;
+        cursor += stock_n;
       }
       const int have = stock_n - stock_next;
       const int take = n_free < have ? n_free : have;

@@ -425,10 +425,10 @@ QC_DEV bool eqp_diagw(CParams& P, const Wrench<4 / G>& Wr, const Cube<4 / G>& C,
 #pragma unroll
   for (int k = 0; k < 6; k++) rhs[k] = 0.0;
 
-  // Face coefficients: with 1-2 feet per lane they stay live across the
-  // factorisation (12-24 VGPRs); with 4 feet per lane (G = 1) they are
+  // Face coefficients: with one foot per lane (G = 4) they stay live across the
+  // factorisation (12 VGPRs); with more feet per lane they are
   // recomputed in pass 2 instead, registers matter more there.
-  constexpr bool KEEP = FPL <= 2;
+  constexpr bool KEEP = FPL <= 1;
   FootCoef kc[FPL];
   // pass 1: this lane's part of sum_i A~_i B_i^-1 A~_i^T and of A p
 #pragma unroll
