@@ -73,6 +73,17 @@ typedef struct qc_batch_in {
    * mit_cheetah_config.yaml:17-18). */
   const double* gait_phase;
   const double* gait_duty;
+  /* ABI v2, optional; all three or none, need joint_q and joint_tau.  Swing-leg references as the reference's
+   * FootTrajectoryManager::referenceState() returns them (WORLD frame foot position / velocity, [n][4][3], read
+   * for swing legs only) and the measured joint velocities [n][4][3].  The swing legs' entries of joint_tau
+   * then hold the reference's swing-leg torque (commander_node.cpp:482-504, 514-526):
+   *   p_b = Rwb^T pos - x (sic), v_b = Rwb^T vel, q_ref = legInverseKinematics(p_b) (kinematics.cpp:117-160),
+   *   qdot_ref = legJacobianInverse(q_ref) v_b (kinematics.cpp:190-204),
+   *   tau = kp o wrapPI(wrap2PI(q_ref) - wrap2PI(q)) + kd o (qdot_ref - qdot) + kff (joint_controller.cpp:21-39),
+   * clamped like the stance torques; it does not depend on the QP's status. */
+  const double* swing_pos;
+  const double* swing_vel;
+  const double* joint_qdot;
 } qc_batch_in;
 
 /* Replaces the returned ForceMap (types.hpp:119; balance_controller.cpp:218-232). */
@@ -96,6 +107,9 @@ typedef struct qc_kinematics {
   double links[12]; /* [leg][l1,l2,l3] signed link lengths  (left_links / right_links)     */
   double tau_min;   /* balance_control/torque_min (-20)                                     */
   double tau_max;   /* balance_control/torque_max (+20)                                     */
+  double jc_kff[3]; /* joint_control/kff (0,0,0)      swing-leg joint PD, commander_node.cpp:314-341, */
+  double jc_kp[3];  /* joint_control/kp  (40,40,50)   mit_cheetah_config.yaml:50-53                   */
+  double jc_kd[3];  /* joint_control/kd  (1,1,1)                                                      */
 } qc_kinematics;
 
 typedef enum qc_status {

@@ -409,6 +409,10 @@ void oracle_default_kinematics(oracle_kinematics* k) {
     }
   k->tau_min = -20.0; /* commander_node.cpp:324 */
   k->tau_max = 20.0;  /* commander_node.cpp:325 */
+  /* joint_control gains, mit_cheetah_config.yaml:50-53 */
+  k->jc_kff[0] = k->jc_kff[1] = k->jc_kff[2] = 0.0;
+  k->jc_kp[0] = 40.0; k->jc_kp[1] = 40.0; k->jc_kp[2] = 50.0;
+  k->jc_kd[0] = k->jc_kd[1] = k->jc_kd[2] = 1.0;
 }
 
 void oracle_leg_fk(const oracle_kinematics* k, int leg, const double* q, double* p) {
@@ -462,4 +466,98 @@ void oracle_tick_batch(const oracle_params* P, const oracle_kinematics* K, long 
       }
     }
   }
+}
+
+/* ------------------------------------------------ swing legs: IK + J^-1 + joint PD */
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+static double normalize_angle_2PI(double angle) { /* math/numerics.cpp:23-35 */
+  const double q = floor(angle / (2.0 * M_PI));
+  angle -= q * 2.0 * M_PI;
+  if (angle < 0.0) angle += 2.0 * M_PI;
+  return angle;
+}
+static double normalize_angle_PI(double rad) { /* math/numerics.cpp:37-50 */
+  const double q = floor((rad + M_PI) / (2.0 * M_PI));
+  rad = (rad + M_PI) - q * 2.0 * M_PI;
+  if (rad < 0) rad += 2.0 * M_PI;
+  return rad - M_PI;
+}
+
+void oracle_leg_ik(const oracle_kinematics* k, int leg, const double* foothold, double* q) {
+  /* kinematics.cpp:117-160; links_ there are the unsigned lengths, right legs are "FR"/"RR" (legs 2, 3) */
+  const double x = foothold[0] - k->hip[3 * leg], y = foothold[1] - k->hip[3 * leg + 1], z = foothold[2] - k->hip[3 * leg + 2];
+  const double l1 = fabs(k->links[3 * leg]), l2 = fabs(k->links[3 * leg + 1]), l3 = fabs(k->links[3 * leg + 2]);
+  double d = (x * x + y * y + z * z - l1 * l1 - l2 * l2 - l3 * l3) / (2.0 * l2 * l3);
+  if (d > 1.0) d = 1.0;
+  double sqrt_component = y * y + z * z - l1 * l1;
+  if (sqrt_component < 0.0) sqrt_component = 0.0;
+  if (k->links[3 * leg] < 0.0) q[0] = atan2(z, y) + atan2(sqrt(sqrt_component), -l1);
+  else q[0] = -(atan2(z, -y) + atan2(sqrt(sqrt_component), -l1));
+  q[2] = atan2(-sqrt(1.0 - d * d), d);
+  q[1] = -atan2(x, sqrt(sqrt_component)) - atan2(l3 * sin(q[2]), l2 + l3 * cos(q[2]));
+}
+
+void oracle_swing_torque(const oracle_kinematics* k, int leg, const double* Rwb, const double* x, const double* pos,
+                         const double* vel, const double* q, const double* qdot, double* tau) {
+  double pb[3], vb[3], qr[3], J[9], Jinv[9], qd[3];
+  for (int r = 0; r < 3; r++) { /* commander_node.cpp:492-493: Rwb.t() * position - x ; Rwb.t() * velocity */
+    pb[r] = Rwb[r] * pos[0] + Rwb[3 + r] * pos[1] + Rwb[6 + r] * pos[2] - x[r];
+    vb[r] = Rwb[r] * vel[0] + Rwb[3 + r] * vel[1] + Rwb[6 + r] * vel[2];
+  }
+  oracle_leg_ik(k, leg, pb, qr);          /* :495 */
+  oracle_leg_jacobian(k, leg, qr, J);     /* legJacobianInverse, kinematics.cpp:190-204 */
+  {
+    /* Gauss-Jordan with partial pivoting (what arma::inv / LAPACK getrf+getri amounts to for a 3x3);
+     * an exactly singular J falls back to J^T (the pinv branch of :196 is not reproduced) */
+    double M[3][6];
+    int singular = 0;
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) { M[i][j] = J[3 * i + j]; M[i][3 + j] = (i == j) ? 1.0 : 0.0; }
+    for (int c = 0; c < 3 && !singular; c++) {
+      int p = c;
+      for (int r = c + 1; r < 3; r++) if (fabs(M[r][c]) > fabs(M[p][c])) p = r;
+      if (M[p][c] == 0.0) { singular = 1; break; }
+      if (p != c) for (int j = 0; j < 6; j++) { double t = M[c][j]; M[c][j] = M[p][j]; M[p][j] = t; }
+      const double piv = M[c][c];
+      for (int j = 0; j < 6; j++) M[c][j] /= piv;
+      for (int r = 0; r < 3; r++) {
+        if (r == c) continue;
+        const double m = M[r][c];
+        for (int j = 0; j < 6; j++) M[r][j] -= m * M[c][j];
+      }
+    }
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) Jinv[3 * i + j] = singular ? J[3 * j + i] : M[i][3 + j];
+  }
+  for (int r = 0; r < 3; r++) qd[r] = Jinv[3 * r] * vb[0] + Jinv[3 * r + 1] * vb[1] + Jinv[3 * r + 2] * vb[2]; /* :496-497 */
+  for (int c = 0; c < 3; c++) { /* joint_controller.cpp:28-36 */
+    const double q_error_normalized = normalize_angle_2PI(qr[c]) - normalize_angle_2PI(q[c]);
+    const double q_error = normalize_angle_PI(q_error_normalized);
+    tau[c] = k->jc_kp[c] * q_error + k->jc_kd[c] * (qd[c] - qdot[c]) + k->jc_kff[c];
+  }
+}
+
+void oracle_tick_swing_batch(const oracle_params* P, const oracle_kinematics* K, long n, const double* Rwb,
+                             const double* Rwb_d, const double* x, const double* xdot, const double* w,
+                             const double* x_d, const double* xdot_d, const double* w_d, const double* joint_q,
+                             const double* joint_qdot, const double* swing_pos, const double* swing_vel,
+                             const unsigned char* stance, double* grf_body, double* joint_tau, int* status, int threads) {
+  oracle_tick_batch(P, K, n, Rwb, Rwb_d, x, xdot, w, x_d, xdot_d, w_d, joint_q, stance, 0, grf_body, joint_tau, status, threads);
+  if (threads < 1) threads = 1;
+#pragma omp parallel for num_threads(threads) schedule(static)
+  for (long i = 0; i < n; i++)
+    for (int leg = 0; leg < 4; leg++) {
+      if (stance[4 * i + leg]) continue; /* commander_node.cpp:485: swing legs only */
+      double tau[3];
+      oracle_swing_torque(K, leg, Rwb + 9 * i, x + 3 * i, swing_pos + 12 * i + 3 * leg, swing_vel + 12 * i + 3 * leg,
+                          joint_q + 12 * i + 3 * leg, joint_qdot + 12 * i + 3 * leg, tau);
+      for (int c = 0; c < 3; c++) { /* merged map clamped at commander_node.cpp:526 */
+        double t = tau[c];
+        if (t < K->tau_min) t = K->tau_min;
+        if (t > K->tau_max) t = K->tau_max;
+        joint_tau[12 * i + 3 * leg + c] = t;
+      }
+    }
 }

@@ -77,6 +77,7 @@ typedef struct oracle_kinematics {
   double hip[12];   /* base -> hip translation per leg */
   double links[12]; /* signed (l1, l2, l3) per leg     */
   double tau_min, tau_max; /* commander_node.cpp:324-325 */
+  double jc_kff[3], jc_kp[3], jc_kd[3]; /* swing-leg joint PD gains, commander_node.cpp:314-341 */
 } oracle_kinematics;
 void oracle_default_kinematics(oracle_kinematics* k);
 /* forwardKinematics(leg, q), kinematics.cpp:81-103 */
@@ -91,6 +92,18 @@ void oracle_tick_batch(const oracle_params* P, const oracle_kinematics* K, long 
                        const double* x_d, const double* xdot_d, const double* w_d, const double* joint_q,
                        const unsigned char* stance, double* feet_out, double* grf_body, double* joint_tau,
                        int* status, int threads);
+/* legInverseKinematics(leg, foothold), kinematics.cpp:117-160 */
+void oracle_leg_ik(const oracle_kinematics* k, int leg, const double* p3, double* q3);
+/* Swing-leg torque of one leg as commander_node.cpp:482-504 + joint_controller.cpp:21-39 compute it (unclamped):
+ * pos/vel = world-frame reference foot state, q/qdot = measured joint state of the leg. */
+void oracle_swing_torque(const oracle_kinematics* k, int leg, const double* Rwb, const double* x, const double* pos,
+                         const double* vel, const double* q3, const double* qdot3, double* tau3);
+/* oracle_tick_batch plus the swing-leg torques merged in (commander_node.cpp:514-526). */
+void oracle_tick_swing_batch(const oracle_params* P, const oracle_kinematics* K, long n, const double* Rwb,
+                             const double* Rwb_d, const double* x, const double* xdot, const double* w,
+                             const double* x_d, const double* xdot_d, const double* w_d, const double* joint_q,
+                             const double* joint_qdot, const double* swing_pos, const double* swing_vel,
+                             const unsigned char* stance, double* grf_body, double* joint_tau, int* status, int threads);
 
 #ifdef __cplusplus
 }

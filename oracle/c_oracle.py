@@ -20,7 +20,8 @@ class OracleParams(C.Structure):
 
 
 class OracleKinematics(C.Structure):
-    _fields_ = [("hip", C.c_double * 12), ("links", C.c_double * 12), ("tau_min", C.c_double), ("tau_max", C.c_double)]
+    _fields_ = [("hip", C.c_double * 12), ("links", C.c_double * 12), ("tau_min", C.c_double), ("tau_max", C.c_double),
+                ("jc_kff", C.c_double * 3), ("jc_kp", C.c_double * 3), ("jc_kd", C.c_double * 3)]
 
 
 def build(force=False):
@@ -136,3 +137,25 @@ def tick_batch(P, batch, kin=None, threads=1, max_iter=200):
     lib().oracle_tick_batch(C.byref(p), C.byref(kin), C.c_long(n), *[_dp(v) for v in a], st.ctypes.data_as(C.POINTER(C.c_ubyte)),
                             _dp(feet), _dp(grf), _dp(tau), status.ctypes.data_as(C.POINTER(C.c_int)), C.c_int(threads))
     return dict(feet=feet, grf_body=grf, joint_tau=tau, status=status)
+
+
+def leg_ik(leg, p, kin=None):
+    kin = kin or default_kinematics()
+    p = np.ascontiguousarray(p, np.float64); q = np.zeros(3)
+    lib().oracle_leg_ik(C.byref(kin), C.c_int(leg), _dp(p), _dp(q))
+    return q
+
+
+def tick_swing_batch(P, batch, kin=None, threads=1, max_iter=200):
+    """tick_batch + swing-leg torques; batch also holds joint_qdot, swing_pos, swing_vel [n,12]."""
+    kin = kin or default_kinematics()
+    p = make_params(P, max_iter)
+    n = batch["x"].shape[0]
+    names = ("Rwb", "Rwb_d", "x", "xdot", "w", "x_d", "xdot_d", "w_d", "joint_q", "joint_qdot", "swing_pos", "swing_vel")
+    a = [np.ascontiguousarray(batch[k], np.float64) for k in names]
+    st = np.ascontiguousarray(batch["stance"], np.uint8)
+    grf = np.zeros((n, 12)); tau = np.zeros((n, 12)); status = np.zeros(n, np.int32)
+    lib().oracle_tick_swing_batch(C.byref(p), C.byref(kin), C.c_long(n), *[_dp(v) for v in a],
+                                  st.ctypes.data_as(C.POINTER(C.c_ubyte)), _dp(grf), _dp(tau),
+                                  status.ctypes.data_as(C.POINTER(C.c_int)), C.c_int(threads))
+    return dict(grf_body=grf, joint_tau=tau, status=status)

@@ -26,7 +26,8 @@ class QcParams(C.Structure):
 
 class QcBatchIn(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in
-                ("Rwb", "Rwb_d", "x", "xdot", "w", "x_d", "xdot_d", "w_d", "feet", "stance", "joint_q", "gait_phase", "gait_duty")]
+                ("Rwb", "Rwb_d", "x", "xdot", "w", "x_d", "xdot_d", "w_d", "feet", "stance", "joint_q", "gait_phase", "gait_duty",
+                 "swing_pos", "swing_vel", "joint_qdot")]
 
 
 class QcBatchOut(C.Structure):
@@ -34,7 +35,8 @@ class QcBatchOut(C.Structure):
 
 
 class QcKinematics(C.Structure):
-    _fields_ = [("hip", C.c_double * 12), ("links", C.c_double * 12), ("tau_min", C.c_double), ("tau_max", C.c_double)]
+    _fields_ = [("hip", C.c_double * 12), ("links", C.c_double * 12), ("tau_min", C.c_double), ("tau_max", C.c_double),
+                ("jc_kff", C.c_double * 3), ("jc_kp", C.c_double * 3), ("jc_kd", C.c_double * 3)]
 
 
 EXPORTS = ("qc_create", "qc_destroy", "qc_control_batch", "qc_control_batch_host", "qc_control",

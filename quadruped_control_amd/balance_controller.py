@@ -61,7 +61,7 @@ class BalanceController:
         return cls(P["mu"], P["mass"], P["fzmin"], P["fzmax"], P["Ib"], P["S"], P["W"], P["kff"],
                    P["kp_p"], P["kd_p"], P["kp_w"], P["kd_w"], **kw)
 
-    def set_kinematics(self, hip=None, links=None, tau_min=None, tau_max=None):
+    def set_kinematics(self, hip=None, links=None, tau_min=None, tau_max=None, jc_kff=None, jc_kp=None, jc_kd=None):
         """Kinematic model of the joint_q / joint_tau extension; unspecified parts keep
         the reference's constants (kinematics.cpp:20-47, commander_node.cpp:324-325)."""
         k = _lib.QcKinematics()
@@ -74,6 +74,9 @@ class BalanceController:
             k.tau_min = float(tau_min)
         if tau_max is not None:
             k.tau_max = float(tau_max)
+        for name, val in (("jc_kff", jc_kff), ("jc_kp", jc_kp), ("jc_kd", jc_kd)):  # swing-leg joint PD gains
+            if val is not None:
+                _fill(getattr(k, name), val, 3, name)
         rc = self._lib.qc_set_kinematics(self._h, C.byref(k))
         if rc != _lib.QC_OK:
             raise RuntimeError(f"qc_set_kinematics failed ({rc}): {_lib.last_error()}")
@@ -156,7 +159,8 @@ class BalanceController:
             if st.dtype != torch.uint8 or not st.is_contiguous() or st.numel() != n * 4 or st.device != dev:
                 raise ValueError("stance: need contiguous uint8 [n,4]")
             bi.stance = st.data_ptr()
-        for name, k in (("gait_phase", 4), ("gait_duty", 1)):  # on-device contact rule (gait.cpp:125-134)
+        for name, k in (("gait_phase", 4), ("gait_duty", 1),  # on-device contact rule (gait.cpp:125-134)
+                        ("swing_pos", 12), ("swing_vel", 12), ("joint_qdot", 12)):  # swing-leg torques
             t = batch.get(name)
             if t is not None:
                 if t.dtype != torch.float64 or not t.is_contiguous() or t.numel() != n * k or t.device != dev:
@@ -204,7 +208,7 @@ class BalanceController:
         for name, _ in _IN_FIELDS + (("joint_q", 12),):
             if batch.get(name) is not None:
                 setattr(bi, name, batch[name].data_ptr())
-        for name in ("stance", "gait_phase", "gait_duty"):
+        for name in ("stance", "gait_phase", "gait_duty", "swing_pos", "swing_vel", "joint_qdot"):
             if batch.get(name) is not None:
                 setattr(bi, name, batch[name].data_ptr())
         bo = _lib.QcBatchOut()
@@ -245,7 +249,7 @@ class BalanceController:
             st = np.ascontiguousarray(st, dtype=np.uint8)
             keep.append(st)
             bi.stance = st.ctypes.data
-        for name in ("gait_phase", "gait_duty"):
+        for name in ("gait_phase", "gait_duty", "swing_pos", "swing_vel", "joint_qdot"):
             if batch.get(name) is not None:
                 a = np.ascontiguousarray(batch[name], dtype=np.float64)
                 keep.append(a)

@@ -288,11 +288,28 @@ QC_DEV void store_from_stock(CParams& P, const BatchIn& in, const BatchOut& out,
       o[3 * i + r] = fb[r];
     }
     if (KIN && out.joint_tau) {  // commander_node.cpp:511-526: tau = clamp(J^T f, tau_min, tau_max)
+      const bool stance_leg = (stance >> (foot0 + i)) & 1u;
+      const double* qp = in.joint_q + 12 * idx + 3 * (foot0 + i);
       double tau[3];
-      leg_jt_force(P, foot0 + i, leg_trig(in.joint_q + 12 * idx + 3 * (foot0 + i)), fb, tau);
+      bool emit = st;
+      if (in.swing_pos && !stance_leg) {  // swing leg: IK + J^-1 + joint PD, commander_node.cpp:482-504
+        const double* sp = in.swing_pos + 12 * idx + 3 * (foot0 + i);
+        const double* sv = in.swing_vel + 12 * idx + 3 * (foot0 + i);
+        const double* xp = in.x + 3 * idx;
+        double pb[3], vb[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+          pb[r] = R[r] * sp[0] + R[3 + r] * sp[1] + R[6 + r] * sp[2] - xp[r];  // Rwb^T pos - x (sic, :492)
+          vb[r] = R[r] * sv[0] + R[3 + r] * sv[1] + R[6 + r] * sv[2];          // Rwb^T vel (:493)
+        }
+        leg_swing_torque(P, foot0 + i, pb, vb, qp, in.joint_qdot + 12 * idx + 3 * (foot0 + i), tau);
+        emit = true;
+      } else {
+        leg_jt_force(P, foot0 + i, leg_trig(qp), fb, tau);
+      }
       double* to = out.joint_tau + 12 * idx + 3 * (foot0 + i);
 #pragma unroll
-      for (int r = 0; r < 3; r++) to[r] = st ? fmin(fmax(tau[r], P.tau_min), P.tau_max) : 0.0;
+      for (int r = 0; r < 3; r++) to[r] = emit ? fmin(fmax(tau[r], P.tau_min), P.tau_max) : 0.0;
     }
   }
   if (member == 0) {
@@ -493,6 +510,10 @@ void qc_default_kinematics(qc_kinematics* k) {
   std::memcpy(k->links, links, sizeof(links));
   k->tau_min = -20.0;  // commander_node.cpp:324-325
   k->tau_max = 20.0;
+  const double kff[3] = {0.0, 0.0, 0.0}, kp[3] = {40.0, 40.0, 50.0}, kd[3] = {1.0, 1.0, 1.0};  // mit_cheetah_config.yaml:50-53
+  std::memcpy(k->jc_kff, kff, sizeof(kff));
+  std::memcpy(k->jc_kp, kp, sizeof(kp));
+  std::memcpy(k->jc_kd, kd, sizeof(kd));
 }
 
 int qc_set_kinematics(qc_handle* h, const qc_kinematics* kin) {
@@ -504,6 +525,9 @@ int qc_set_kinematics(qc_handle* h, const qc_kinematics* kin) {
   std::memcpy(h->dp.links, k.links, sizeof(k.links));
   h->dp.tau_min = k.tau_min;
   h->dp.tau_max = k.tau_max;
+  std::memcpy(h->dp.jc_kff, k.jc_kff, sizeof(k.jc_kff));
+  std::memcpy(h->dp.jc_kp, k.jc_kp, sizeof(k.jc_kp));
+  std::memcpy(h->dp.jc_kd, k.jc_kd, sizeof(k.jc_kd));
   QC_HIP(hipSetDevice(h->device));
   QC_HIP(hipMemcpy(h->d_params, &h->dp, sizeof(qc::DevParams), hipMemcpyHostToDevice));  // synchronous: no launch races it
   return QC_OK;
@@ -590,6 +614,9 @@ int qc_create(const qc_params* p, int device, qc_handle** out) {
     std::memcpy(d.links, k.links, sizeof(k.links));
     d.tau_min = k.tau_min;
     d.tau_max = k.tau_max;
+    std::memcpy(d.jc_kff, k.jc_kff, sizeof(k.jc_kff));
+    std::memcpy(d.jc_kp, k.jc_kp, sizeof(k.jc_kp));
+    std::memcpy(d.jc_kd, k.jc_kd, sizeof(k.jc_kd));
   }
   d.stance_phase = 0.8 / (0.18 + 0.8);  // mit_cheetah_config.yaml:17-18
   d.tol_d = 1e-12;  // relative to 1+|grad|_inf: W ~ 1e-5 makes the primal very sensitive to a wrongly kept weakly-active face
@@ -632,8 +659,11 @@ int qc_control_batch(qc_handle* h, size_t n, const qc_batch_in* in, const uint32
   if (out->joint_tau && !in->joint_q) return fail(QC_ERR_INVALID, "qc_control_batch: joint_tau needs joint_q");
   QC_HIP(hipSetDevice(h->device));
   const bool kin = in->joint_q != nullptr;
+  const int n_sw = (in->swing_pos ? 1 : 0) + (in->swing_vel ? 1 : 0) + (in->joint_qdot ? 1 : 0);
+  if (n_sw != 0 && (n_sw != 3 || !in->joint_q || !out->joint_tau))
+    return fail(QC_ERR_INVALID, "qc_control_batch: swing_pos, swing_vel and joint_qdot go together and need joint_q and joint_tau");
   qc::BatchIn bi{in->Rwb, in->Rwb_d, in->x, in->xdot, in->w, in->x_d, in->xdot_d, in->w_d, in->feet, in->stance, in->joint_q,
-                 in->gait_phase, in->gait_duty};
+                 in->gait_phase, in->gait_duty, in->swing_pos, in->swing_vel, in->joint_qdot};
   qc::BatchOut bo{out->grf_body, out->status, out->active_set, out->iterations, out->joint_tau};
   // One wave per 64-thread block; a group of G lanes per robot.  The group
   // width trades latency for throughput: G = 4 (foot per lane) cuts the serial
@@ -686,7 +716,7 @@ int qc_control_batch_host(qc_handle* h, size_t n, const qc_batch_in* in, const u
   QC_HIP(hipSetDevice(h->device));
   if (!h->stream) QC_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   // layout (all 8-byte aligned): 48 doubles in, 12 doubles out, 4 x 4-byte words
-  const size_t per = 48 * 8 + 12 * 8 + 4 * 4 + 8 + 12 * 8 + 12 * 8 + 5 * 8;
+  const size_t per = 48 * 8 + 12 * 8 + 4 * 4 + 8 + 12 * 8 + 12 * 8 + 5 * 8 + 3 * 12 * 8;
   const size_t need = n * per + 256;
   if (need > h->stage_bytes) {
     if (h->stage) QC_HIP(hipFree(h->stage));
@@ -721,6 +751,13 @@ int qc_control_batch_host(qc_handle* h, size_t n, const qc_batch_in* in, const u
     d_gd = (double*)carve(n * 8);
     QC_HIP(hipMemcpyAsync(d_gd, in->gait_duty, n * 8, hipMemcpyHostToDevice, h->stream));
   }
+  const double* sw_src[3] = {in->swing_pos, in->swing_vel, in->joint_qdot};
+  double* d_sw[3] = {nullptr, nullptr, nullptr};
+  for (int k = 0; k < 3; k++)
+    if (sw_src[k]) {
+      d_sw[k] = (double*)carve(n * 12 * 8);
+      QC_HIP(hipMemcpyAsync(d_sw[k], sw_src[k], n * 12 * 8, hipMemcpyHostToDevice, h->stream));
+    }
   uint8_t* d_st = nullptr;
   if (in->stance) {
     d_st = (uint8_t*)carve(n * 4);
@@ -736,7 +773,7 @@ int qc_control_batch_host(qc_handle* h, size_t n, const qc_batch_in* in, const u
   uint32_t* d_act = out->active_set ? (uint32_t*)carve(n * 4) : nullptr;
   int32_t* d_it = out->iterations ? (int32_t*)carve(n * 4) : nullptr;
   if (off > h->stage_bytes) return fail(QC_ERR_INVALID, "qc_control_batch_host: staging overflow");
-  qc_batch_in din{dptr[0], dptr[1], dptr[2], dptr[3], dptr[4], dptr[5], dptr[6], dptr[7], dptr[8], d_st, d_q, d_gp, d_gd};
+  qc_batch_in din{dptr[0], dptr[1], dptr[2], dptr[3], dptr[4], dptr[5], dptr[6], dptr[7], dptr[8], d_st, d_q, d_gp, d_gd, d_sw[0], d_sw[1], d_sw[2]};
   qc_batch_out dout{d_grf, d_status, d_act, d_it, d_tau};
   int rc = qc_control_batch(h, n, &din, d_warm, &dout, h->stream);
   if (rc != QC_OK) return rc;
@@ -752,7 +789,7 @@ int qc_control_batch_host(qc_handle* h, size_t n, const qc_batch_in* in, const u
 int qc_control(qc_handle* h, const double* Rwb, const double* Rwb_d, const double* x, const double* xdot,
                const double* w, const double* x_d, const double* xdot_d, const double* w_d, const double* feet,
                const uint8_t* stance, double* grf_body, int32_t* status) {
-  qc_batch_in in{Rwb, Rwb_d, x, xdot, w, x_d, xdot_d, w_d, feet, stance, nullptr, nullptr, nullptr};
+  qc_batch_in in{Rwb, Rwb_d, x, xdot, w, x_d, xdot_d, w_d, feet, stance, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   qc_batch_out out{grf_body, status, nullptr, nullptr, nullptr};
   return qc_control_batch_host(h, 1, &in, nullptr, &out);
 }

@@ -45,6 +45,7 @@ struct DevParams {
   double hip[12];      // [leg][xyz] base -> hip
   double links[12];    // [leg][l1,l2,l3] signed
   double tau_min, tau_max;
+  double jc_kff[3], jc_kp[3], jc_kd[3];  // swing-leg joint PD (joint_controller.cpp)
   double stance_phase; // gait.cpp:45, default duty of the on-device contact rule
   double tol_d;        // relative multiplier tolerance
   int max_iter;
@@ -70,6 +71,9 @@ struct BatchIn {
   const double* joint_q;
   const double* gait_phase;
   const double* gait_duty;
+  const double* swing_pos;
+  const double* swing_vel;
+  const double* joint_qdot;
 };
 struct BatchOut {
   double* grf_body;
@@ -232,6 +236,63 @@ QC_DEV void leg_jt_force(CParams& P, int leg, const LegTrig& t, const double (&f
   tau[0] = j10 * f[1] + j20 * f[2];  // jac(0,0) = 0
   tau[1] = j01 * f[0] + j11 * f[1] + j21 * f[2];
   tau[2] = j02 * f[0] + j12 * f[1] + j22 * f[2];
+}
+
+// math/numerics.cpp:23-50
+QC_DEV double normalize_angle_2PI(double angle) {
+  const double two_pi = 2.0 * 3.14159265358979323846;
+  angle -= floor(angle / two_pi) * two_pi;
+  if (angle < 0.0) angle += two_pi;
+  return angle;
+}
+QC_DEV double normalize_angle_PI(double rad) {
+  const double pi = 3.14159265358979323846, two_pi = 2.0 * pi;
+  const double qf = floor((rad + pi) / two_pi);
+  rad = (rad + pi) - qf * two_pi;
+  if (rad < 0.0) rad += two_pi;
+  return rad - pi;
+}
+// Swing-leg torque of one leg, commander_node.cpp:482-504 + joint_controller.cpp:21-39.
+// pb, vb: desired foot position / velocity in the frame the reference hands to IK.
+QC_DEV void leg_swing_torque(CParams& P, int leg, const double (&pb)[3], const double (&vb)[3], const double* __restrict__ q,
+                             const double* __restrict__ qdot, double (&tau)[3]) {
+  // legInverseKinematics, kinematics.cpp:117-160 (unsigned link lengths; right legs have links[0] < 0)
+  const double l1 = fabs(P.links[3 * leg]), l2 = fabs(P.links[3 * leg + 1]), l3 = fabs(P.links[3 * leg + 2]);
+  const bool right = P.links[3 * leg] < 0.0;
+  const double x = pb[0] - P.hip[3 * leg], y = pb[1] - P.hip[3 * leg + 1], z = pb[2] - P.hip[3 * leg + 2];
+  double d = (x * x + y * y + z * z - l1 * l1 - l2 * l2 - l3 * l3) / (2.0 * l2 * l3);
+  if (d > 1.0) d = 1.0;
+  double sc = y * y + z * z - l1 * l1;
+  if (sc < 0.0) sc = 0.0;
+  const double rt = sqrt(sc);
+  double qr[3];
+  qr[0] = right ? atan2(z, y) + atan2(rt, -l1) : -(atan2(z, -y) + atan2(rt, -l1));
+  qr[2] = atan2(-sqrt(1.0 - d * d), d);
+  qr[1] = -atan2(x, rt) - atan2(l3 * sin(qr[2]), l2 + l3 * cos(qr[2]));
+  // legJacobianInverse(q_ref) * vb, kinematics.cpp:190-204 (closed-form inverse; J^T if exactly singular)
+  const LegTrig t = leg_trig(qr);
+  const double L1 = P.links[3 * leg], L2 = P.links[3 * leg + 1], L3 = P.links[3 * leg + 2];
+  const double a = L2 * t.c2 + L3 * t.c23, b = L2 * t.s2 + L3 * t.s23;
+  const double J[9] = {0.0, a, L3 * t.c23, -L1 * t.s1 - a * t.c1, b * t.s1, L3 * t.s1 * t.s23, L1 * t.c1 - a * t.s1, -b * t.c1, -L3 * t.s23 * t.c1};
+  const double c00 = J[4] * J[8] - J[5] * J[7], c01 = J[5] * J[6] - J[3] * J[8], c02 = J[3] * J[7] - J[4] * J[6];
+  const double det = J[0] * c00 + J[1] * c01 + J[2] * c02;
+  double qd[3];
+  if (det != 0.0) {
+    const double id = 1.0 / det;
+    // inverse = adj / det; row r of the inverse dotted with vb
+    qd[0] = id * (c00 * vb[0] + (J[2] * J[7] - J[1] * J[8]) * vb[1] + (J[1] * J[5] - J[2] * J[4]) * vb[2]);
+    qd[1] = id * (c01 * vb[0] + (J[0] * J[8] - J[2] * J[6]) * vb[1] + (J[2] * J[3] - J[0] * J[5]) * vb[2]);
+    qd[2] = id * (c02 * vb[0] + (J[1] * J[6] - J[0] * J[7]) * vb[1] + (J[0] * J[4] - J[1] * J[3]) * vb[2]);
+  } else {
+#pragma unroll
+    for (int c = 0; c < 3; c++) qd[c] = J[c] * vb[0] + J[3 + c] * vb[1] + J[6 + c] * vb[2];
+  }
+  // JointController::control, joint_controller.cpp:28-36
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    const double e = normalize_angle_PI(normalize_angle_2PI(qr[c]) - normalize_angle_2PI(q[c]));
+    tau[c] = P.jc_kp[c] * e + P.jc_kd[c] * (qd[c] - qdot[c]) + P.jc_kff[c];
+  }
 }
 
 // K0 + K2 + K3 of SURVEY.md 2.2: gather, PD wrench law, SRB dynamics rhs.

@@ -176,3 +176,31 @@ def with_joint_angles(batch, seed=0x5EED0006, start=0):
     out = {k: v for k, v in batch.items() if k != "feet"}
     out["joint_q"] = np.ascontiguousarray(q)
     return out
+
+
+def with_swing_references(batch, seed=0x5EED0007, start=0):
+    """Add swing-leg references to a batch that already holds joint_q: world-frame reference foot
+    positions / velocities (what FootTrajectoryManager::referenceState returns) placed near the current
+    feet, and measured joint velocities.  Positions are built so that the frame change of
+    commander_node.cpp:492 (Rwb^T pos - x) lands on a reachable body-frame target."""
+    from . import gait  # noqa: F401
+
+    n = batch["x"].shape[0]
+    idx = np.arange(start, start + n, dtype=np.uint64)
+    q_t = batch["joint_q"] + _uvec(seed, idx, 60, 12, -0.15, 0.15)      # target joint angles
+    hip = np.array([[-0.196, 0.05, 0.0], [0.196, 0.05, 0.0], [-0.196, -0.05, 0.0], [0.196, -0.05, 0.0]])
+    links = np.array([[0.077, -0.211, -0.230]] * 2 + [[-0.077, -0.211, -0.230]] * 2)
+    qq = q_t.reshape(n, 4, 3)
+    t1, t2, t3 = qq[..., 0], qq[..., 1], qq[..., 2]
+    l1, l2, l3 = links[None, :, 0], links[None, :, 1], links[None, :, 2]
+    pb = np.stack([l2 * np.sin(t2) + l3 * np.sin(t2 + t3) + hip[None, :, 0],
+                   l1 * np.cos(t1) - l2 * np.sin(t1) * np.cos(t2) - l3 * np.sin(t1) * np.cos(t2 + t3) + hip[None, :, 1],
+                   l1 * np.sin(t1) + l2 * np.cos(t1) * np.cos(t2) + l3 * np.cos(t1) * np.cos(t2 + t3) + hip[None, :, 2]], axis=-1)
+    R = batch["Rwb"].reshape(n, 3, 3)
+    pos = np.einsum("nij,nkj->nki", R, pb + batch["x"][:, None, :])      # pos = Rwb (p_b + x)
+    vel = _uvec(seed, idx, 80, 12, -0.5, 0.5).reshape(n, 4, 3)
+    out = dict(batch)
+    out["swing_pos"] = np.ascontiguousarray(pos.reshape(n, 12))
+    out["swing_vel"] = np.ascontiguousarray(vel.reshape(n, 12))
+    out["joint_qdot"] = np.ascontiguousarray(_uvec(seed, idx, 100, 12, -2.0, 2.0))
+    return out

@@ -337,3 +337,32 @@ def test_graph_capture_replay(q):
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out_s["grf_body"], ref)
+
+
+@pytest.mark.parametrize("n", [900, 40000])
+def test_swing_leg_torques(q, n):
+    """SURVEY 8f rank 4 (stateless part): swing legs get IK + J^-1 + joint-PD torques
+    (commander_node.cpp:482-504), stance legs keep J^T f; merged and clamped like :514-526."""
+    from oracle import c_oracle as O
+    from quadruped_control_amd import workloads as W
+
+    P = q.cheetah_params(0.6)
+    b = W.with_swing_references(W.with_joint_angles(W.config3(n)))
+    ctl = q.BalanceController.from_params(P)
+    o = ctl.control_batch_host(b, want_torques=True)
+    ref = O.tick_swing_batch(P, b, threads=8)
+    assert (o["status"] == 0).all()
+    assert np.max(np.abs(o["joint_tau"] - ref["joint_tau"])) < 1e-6 * 20.0
+    sw = np.repeat(b["stance"] == 0, 3, axis=1)
+    assert np.any(o["joint_tau"][sw] != 0.0)
+    # custom joint PD gains
+    ctl.set_kinematics(jc_kp=[10.0, 20.0, 30.0], jc_kd=[0.5, 0.5, 0.5], jc_kff=[0.1, 0.2, 0.3])
+    kin = O.default_kinematics()
+    kin.jc_kp[:] = [10.0, 20.0, 30.0]; kin.jc_kd[:] = [0.5, 0.5, 0.5]; kin.jc_kff[:] = [0.1, 0.2, 0.3]
+    o2 = ctl.control_batch_host(b, want_torques=True)
+    ref2 = O.tick_swing_batch(P, b, kin=kin, threads=8)
+    assert np.max(np.abs(o2["joint_tau"] - ref2["joint_tau"])) < 1e-6 * 20.0
+    # the three swing inputs go together
+    bad = {k: v for k, v in b.items() if k != "swing_vel"}
+    with pytest.raises(RuntimeError, match="go together"):
+        ctl.control_batch_host(bad, want_torques=True)

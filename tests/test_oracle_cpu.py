@@ -160,3 +160,34 @@ def test_tick_composition():
             tau = O.leg_jacobian(leg, b["joint_q"][i, 3 * leg:3 * leg + 3]).T @ grf[i, 3 * leg:3 * leg + 3]
             exp = np.clip(tau, -20.0, 20.0) if b["stance"][i, leg] else np.zeros(3)
             np.testing.assert_allclose(t["joint_tau"][i, 3 * leg:3 * leg + 3], exp, atol=1e-12)
+
+
+def test_inverse_kinematics_round_trip():
+    """legInverseKinematics (kinematics.cpp:117-160) inverts forwardKinematics (:81-103)
+    on the knee-bent branch the reference assumes (calf angle in (-pi, 0))."""
+    rng = np.random.default_rng(9)
+    for _ in range(200):
+        q = np.array([rng.uniform(-0.6, 0.6), rng.uniform(-0.2, 1.4), rng.uniform(-2.4, -0.3)])
+        for leg in range(4):
+            p = O.leg_fk(leg, q)
+            np.testing.assert_allclose(O.leg_ik(leg, p), q, atol=1e-9)
+            np.testing.assert_allclose(O.leg_fk(leg, O.leg_ik(leg, p)), p, atol=1e-12)
+
+
+def test_swing_torque_composition():
+    P = R.cheetah_params(0.6)
+    b = W.with_swing_references(W.with_joint_angles(W.config3(256)))
+    t = O.tick_swing_batch(P, b)
+    base = O.tick_batch(P, b)
+    st = np.repeat(b["stance"] == 1, 3, axis=1)
+    np.testing.assert_array_equal(t["joint_tau"][st], base["joint_tau"][st])       # stance legs untouched
+    assert np.all(np.abs(t["joint_tau"]) <= 20.0) and np.any(t["joint_tau"][~st] != 0.0)
+    # zero velocity references and measured state at the target -> only the kff term (0) remains
+    b0 = dict(b)
+    b0["swing_vel"] = np.zeros_like(b["swing_vel"]); b0["joint_qdot"] = np.zeros_like(b["joint_qdot"])
+    n = 256
+    Rm = b["Rwb"].reshape(n, 3, 3)
+    pb = np.einsum("nji,nkj->nki", Rm, b["swing_pos"].reshape(n, 4, 3)) - b["x"][:, None, :]
+    b0["joint_q"] = np.stack([np.concatenate([O.leg_ik(leg, pb[i, leg]) for leg in range(4)]) for i in range(n)])
+    t0 = O.tick_swing_batch(P, b0)
+    assert np.max(np.abs(t0["joint_tau"][~st])) < 1e-9
