@@ -31,11 +31,12 @@ namespace qc {
 //
 // A wavefront owns a contiguous chunk of robots and walks through it: all
 // lanes execute the same working-set recalculation in lockstep (straight-line,
-// select-based code, no per-lane branches); groups whose robot has converged
-// park their result and, once `refill_t` groups are parked, the wave flushes
-// their outputs and hands them the next robots of the chunk.  This keeps the
-// lanes busy although robots need between 1 and ~20 recalculations.
-// LDS stock planes (see the dense phases below)
+// select-based code, no per-lane branches); a group whose robot has converged
+// pushes the result to the wave's output stock and, once `refill_t` lanes are
+// free, free groups pull the next robots from the wave's input stock.  This
+// keeps the lanes busy although robots need between 1 and ~20 recalculations.
+//
+// LDS stock planes (see "Dense phases around the divergent solve" below).
 // SP = plane stride in doubles: 65, not 64, so that the lanes of one group (same
 // slot, planes 3*FPL apart) fall into different banks; the dense side
 // (plane[f][lane]) is conflict-free either way.
