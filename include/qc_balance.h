@@ -84,7 +84,23 @@ typedef struct qc_batch_in {
   const double* swing_pos;
   const double* swing_vel;
   const double* joint_qdot;
+  /* ABI v2, optional, IN/OUT: persistent per-robot swing-planning state [n] (zero-initialise with
+   * qc_swing_state_init before the first tick).  When given (needs joint_q, joint_qdot, gait_phase and
+   * joint_tau; swing_pos/swing_vel must be NULL) the swing references are generated on the device the way
+   * the reference's loop does it (commander_node.cpp:432-471): FootPlanner::positions / updateStates /
+   * singleFoot (foot_planner.cpp:46-157: replan a foothold when a leg goes stance -> swing, Raibert + LIP
+   * heuristic), FootTrajectoryManager::referenceStates / referenceState and the sextic FootTrajectory
+   * (trajectory.cpp:220-277, 308-388), then fed to the swing-leg torque chain above. */
+  struct qc_swing_state* swing_state;
 } qc_batch_in;
+
+/* FootPlanner::state_map_ (foot_planner.hpp) + FootTrajectoryManager::traj_map_ (trajectory.hpp), per robot. */
+typedef struct qc_swing_state {
+  int32_t leg_state[4];  /* LegState seen at the previous tick, -1 = none yet (state_map_ empty)     */
+  int32_t has_traj[4];   /* leg has an entry in traj_map_                                            */
+  double p_start[12];    /* [leg][xyz] world-frame trajectory start  (FootTrajBounds, types.hpp:52-66) */
+  double p_final[12];    /* [leg][xyz] world-frame planned foothold                                   */
+} qc_swing_state;
 
 /* Replaces the returned ForceMap (types.hpp:119; balance_controller.cpp:218-232). */
 typedef struct qc_batch_out {
@@ -110,6 +126,9 @@ typedef struct qc_kinematics {
   double jc_kff[3]; /* joint_control/kff (0,0,0)      swing-leg joint PD, commander_node.cpp:314-341, */
   double jc_kp[3];  /* joint_control/kp  (40,40,50)   mit_cheetah_config.yaml:50-53                   */
   double jc_kd[3];  /* joint_control/kd  (1,1,1)                                                      */
+  double planner_hip[12]; /* [leg][xyz] base -> thigh used by FootPlanner (foot_planner.cpp:27-42)          */
+  double planner_k;       /* Raibert feedback gain k_ (foot_planner.cpp:25, 0.01)                            */
+  double swing_height;    /* gait/height: apex of the swing trajectory (commander_node.cpp:247, 0.08)        */
 } qc_kinematics;
 
 typedef enum qc_status {
@@ -158,6 +177,8 @@ void qc_default_kinematics(qc_kinematics* out);
 int qc_set_kinematics(qc_handle* h, const qc_kinematics* kin);
 /* Default stance_phase for qc_batch_in.gait_phase: t_stance / (t_swing + t_stance), GaitScheduler ctor gait.cpp:36-46. */
 int qc_set_gait(qc_handle* h, double t_swing, double t_stance);
+/* Host helper: the "nothing planned yet" value of qc_swing_state for n robots (host memory). */
+void qc_swing_state_init(struct qc_swing_state* states, size_t n);
 
 /* Thread-local message of the last failing call (ROS_ERROR replacement,
  * balance_controller.cpp:157,184,199,214). */

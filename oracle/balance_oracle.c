@@ -413,6 +413,16 @@ void oracle_default_kinematics(oracle_kinematics* k) {
   k->jc_kff[0] = k->jc_kff[1] = k->jc_kff[2] = 0.0;
   k->jc_kp[0] = 40.0; k->jc_kp[1] = 40.0; k->jc_kp[2] = 50.0;
   k->jc_kd[0] = k->jc_kd[1] = k->jc_kd[2] = 1.0;
+  {
+    const double xbt = 0.196, ybt = 0.127, zbt = 0.0; /* foot_planner.cpp:27-42 */
+    const double hp[4][3] = {{-xbt, ybt, zbt}, {xbt, ybt, zbt}, {-xbt, -ybt, zbt}, {xbt, -ybt, zbt}};
+    for (int leg = 0; leg < 4; leg++)
+      for (int c = 0; c < 3; c++) k->planner_hip[3 * leg + c] = hp[leg][c];
+  }
+  k->planner_k = 0.01;    /* foot_planner.cpp:25 */
+  k->swing_height = 0.08; /* gait/height */
+  k->t_swing = 0.18;      /* mit_cheetah_config.yaml:17-18 */
+  k->t_stance = 0.8;
 }
 
 void oracle_leg_fk(const oracle_kinematics* k, int leg, const double* q, double* p) {
@@ -509,10 +519,15 @@ void oracle_swing_torque(const oracle_kinematics* k, int leg, const double* Rwb,
   oracle_leg_ik(k, leg, pb, qr);          /* :495 */
   oracle_leg_jacobian(k, leg, qr, J);     /* legJacobianInverse, kinematics.cpp:190-204 */
   {
-    /* Gauss-Jordan with partial pivoting (what arma::inv / LAPACK getrf+getri amounts to for a 3x3);
-     * an exactly singular J falls back to J^T (the pinv branch of :196 is not reproduced) */
+    /* Gauss-Jordan with partial pivoting (what arma::inv / LAPACK getrf+getri amounts to for a 3x3).
+     * A numerically singular J (leg fully stretched: the reference point is out of reach and IK clamps
+     * d to 1) gives a LAPACK-dependent garbage inverse in the reference; the restatement - and the device
+     * code - take the reference's last-resort branch J^T (:198) when |det| <= 1e-9 (|l1|+|l2|+|l3|)^3
+     * (the pinv branch of :196 is not reproduced). */
     double M[3][6];
-    int singular = 0;
+    const double det = J[0] * (J[4] * J[8] - J[5] * J[7]) + J[1] * (J[5] * J[6] - J[3] * J[8]) + J[2] * (J[3] * J[7] - J[4] * J[6]);
+    const double lsum = fabs(k->links[3 * leg]) + fabs(k->links[3 * leg + 1]) + fabs(k->links[3 * leg + 2]);
+    int singular = !(fabs(det) > 1.0e-9 * lsum * lsum * lsum);
     for (int i = 0; i < 3; i++)
       for (int j = 0; j < 3; j++) { M[i][j] = J[3 * i + j]; M[i][3 + j] = (i == j) ? 1.0 : 0.0; }
     for (int c = 0; c < 3 && !singular; c++) {
@@ -560,4 +575,121 @@ void oracle_tick_swing_batch(const oracle_params* P, const oracle_kinematics* K,
         joint_tau[12 * i + 3 * leg + c] = t;
       }
     }
+}
+
+/* ------------------------------------------------ swing references: planner + sextic trajectories */
+static void single_foot(const oracle_kinematics* K, int leg, const double* Rwb, const double* x, const double* xdot,
+                        const double* w, const double* xdot_d, const double* foot_position, double* foothold) {
+  /* FootPlanner::singleFoot, foot_planner.cpp:76-104 */
+  double p_thigh[3], pcom_foot[3], tang_vel[3];
+  mat3_vec(Rwb, K->planner_hip + 3 * leg, p_thigh);
+  for (int r = 0; r < 3; r++) p_thigh[r] += x[r];
+  mat3_vec(Rwb, foot_position, pcom_foot);
+  tang_vel[0] = w[1] * pcom_foot[2] - w[2] * pcom_foot[1];
+  tang_vel[1] = w[2] * pcom_foot[0] - w[0] * pcom_foot[2];
+  tang_vel[2] = w[0] * pcom_foot[1] - w[1] * pcom_foot[0];
+  for (int r = 0; r < 3; r++) {
+    const double p_linear = (K->t_stance / 2.0) * xdot[r] + K->planner_k * (xdot[r] - xdot_d[r]);
+    const double p_tangent = (K->t_stance / 2.0) * tang_vel[r];
+    const double p_lip = 0.5 * sqrt(x[2] / 9.81) * xdot[r];
+    foothold[r] = p_thigh[r] + p_linear + p_tangent + p_lip;
+  }
+  foothold[2] = 0.0;
+}
+
+static void sextic_coefficients(const double* p_start, const double* p_center, const double* p_final, double coef[7][3]) {
+  /* FootTrajectory::initSystem / constantTerms / generateTrajetory, trajectory.cpp:220-225, 256-296:
+   * arma::solve(A, B) restated as Gaussian elimination with partial pivoting */
+  double M[7][10] = {{1, 0, 0, 0, 0, 0, 0}, {1, 1, 1, 1, 1, 1, 1}, {1, 0.5, 0.25, 0.125, 0.0625, 0.03125, 0.015625},
+                     {0, 1, 0, 0, 0, 0, 0}, {0, 1, 2, 3, 4, 5, 6}, {0, 0, 2, 0, 0, 0, 0}, {0, 0, 2, 6, 12, 20, 30}};
+  for (int i = 0; i < 7; i++)
+    for (int c = 0; c < 3; c++) M[i][7 + c] = (i == 0) ? p_start[c] : (i == 1 ? p_final[c] : (i == 2 ? p_center[c] : 0.0));
+  for (int c = 0; c < 7; c++) {
+    int p = c;
+    for (int r = c + 1; r < 7; r++) if (fabs(M[r][c]) > fabs(M[p][c])) p = r;
+    if (p != c) for (int j = 0; j < 10; j++) { double t = M[c][j]; M[c][j] = M[p][j]; M[p][j] = t; }
+    for (int r = c + 1; r < 7; r++) {
+      const double m = M[r][c] / M[c][c];
+      for (int j = c; j < 10; j++) M[r][j] -= m * M[c][j];
+    }
+  }
+  for (int r = 6; r >= 0; r--)
+    for (int c = 0; c < 3; c++) {
+      double s2 = M[r][7 + c];
+      for (int j = r + 1; j < 7; j++) s2 -= M[r][j] * coef[j][c];
+      coef[r][c] = s2 / M[r][r];
+    }
+}
+
+static void reference_state(const oracle_kinematics* K, const oracle_swing_state* st, int leg, double phase, double* pos, double* vel) {
+  /* FootTrajectoryManager::referenceState, trajectory.cpp:360-388 */
+  pos[0] = pos[1] = pos[2] = vel[0] = vel[1] = vel[2] = 0.0;
+  if (!st->has_traj[leg]) return; /* FootState() */
+  const double stance_phase = K->t_stance / (K->t_swing + K->t_stance); /* :303 */
+  const double slope = 1.0 / (1.0 - stance_phase), y_intercept = 1.0 - slope;
+  double t = slope * phase + y_intercept;
+  if (t < 0.0) t = 0.0;
+  if (t > 1.0) t = 1.0;
+  double p_center[3], coef[7][3];
+  for (int c = 0; c < 3; c++) p_center[c] = (st->p_start[3 * leg + c] + st->p_final[3 * leg + c]) / 2.0; /* :325 */
+  p_center[2] = K->swing_height;                                                                         /* :326 */
+  sextic_coefficients(st->p_start + 3 * leg, p_center, st->p_final + 3 * leg, coef);
+  /* trackTrajectory, trajectory.cpp:227-254 */
+  const double pf[7] = {1.0, t, pow(t, 2), pow(t, 3), pow(t, 4), pow(t, 5), pow(t, 6)};
+  const double vf[7] = {0.0, 1.0, 2.0 * t, 3.0 * pow(t, 2), 4.0 * pow(t, 3), 5.0 * pow(t, 4), 6.0 * pow(t, 5)};
+  for (int j = 0; j < 7; j++)
+    for (int c = 0; c < 3; c++) { pos[c] += pf[j] * coef[j][c]; vel[c] += vf[j] * coef[j][c]; }
+}
+
+void oracle_swing_references(const oracle_kinematics* K, oracle_swing_state* st, const double* Rwb, const double* x,
+                             const double* xdot, const double* w, const double* xdot_d, const double* feet_body,
+                             const unsigned char* stance, const double* phase, double* pos, double* vel) {
+  /* FootPlanner::updateStates, foot_planner.cpp:106-157 */
+  int plan[4] = {0, 0, 0, 0}, any = 0;
+  const int empty = st->leg_state[0] < 0;
+  for (int leg = 0; leg < 4; leg++) {
+    const int now = stance[leg] ? 1 : 0;
+    if (empty) { if (!now) plan[leg] = 1; }
+    else if (st->leg_state[leg] == 1 && !now) plan[leg] = 1;
+    st->leg_state[leg] = now;
+    any |= plan[leg];
+  }
+  if (any) { /* commander_node.cpp:450-462 -> referenceStates(gait_map, bounds): traj_map_.clear() then the planned legs */
+    for (int leg = 0; leg < 4; leg++) {
+      st->has_traj[leg] = plan[leg];
+      if (!plan[leg]) continue;
+      double ps[3];
+      mat3_vec(Rwb, feet_body + 3 * leg, ps);
+      for (int r = 0; r < 3; r++) st->p_start[3 * leg + r] = ps[r] + x[r]; /* :456 */
+      single_foot(K, leg, Rwb, x, xdot, w, xdot_d, feet_body + 3 * leg, st->p_final + 3 * leg);
+    }
+  }
+  for (int leg = 0; leg < 4; leg++) {
+    for (int c = 0; c < 3; c++) pos[3 * leg + c] = vel[3 * leg + c] = 0.0;
+    if (!stance[leg]) reference_state(K, st, leg, phase[leg], pos + 3 * leg, vel + 3 * leg); /* :485-489 */
+  }
+}
+
+void oracle_tick_planned_batch(const oracle_params* P, const oracle_kinematics* K, long n, oracle_swing_state* states,
+                               const double* Rwb, const double* Rwb_d, const double* x, const double* xdot,
+                               const double* w, const double* x_d, const double* xdot_d, const double* w_d,
+                               const double* joint_q, const double* joint_qdot, const double* gait_phase,
+                               double* grf_body, double* joint_tau, int* status, int threads) {
+  if (threads < 1) threads = 1;
+  const double duty = K->t_stance / (K->t_swing + K->t_stance); /* gait.cpp:45 */
+#pragma omp parallel for num_threads(threads) schedule(static)
+  for (long i = 0; i < n; i++) {
+    unsigned char stance[4];
+    double feet[12], pos[12], vel[12];
+    for (int leg = 0; leg < 4; leg++) {
+      const double ph = gait_phase[4 * i + leg]; /* GaitScheduler::phase, gait.cpp:125-134 */
+      stance[leg] = ((ph > 0.0 || fabs(ph - 0.0) < 1.0e-12) && (ph < duty || fabs(ph - duty) < 1.0e-12)) ? 1 : 0;
+      oracle_leg_fk(K, leg, joint_q + 12 * i + 3 * leg, feet + 3 * leg);
+    }
+    oracle_swing_references(K, states + i, Rwb + 9 * i, x + 3 * i, xdot + 3 * i, w + 3 * i, xdot_d + 3 * i, feet, stance,
+                            gait_phase + 4 * i, pos, vel);
+    oracle_tick_swing_batch(P, K, 1, Rwb + 9 * i, Rwb_d + 9 * i, x + 3 * i, xdot + 3 * i, w + 3 * i, x_d + 3 * i, xdot_d + 3 * i,
+                            w_d + 3 * i, joint_q + 12 * i, joint_qdot + 12 * i, pos, vel, stance, grf_body + 12 * i,
+                            joint_tau + 12 * i, status ? status + i : 0, 1);
+  }
 }

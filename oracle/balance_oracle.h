@@ -78,6 +78,8 @@ typedef struct oracle_kinematics {
   double links[12]; /* signed (l1, l2, l3) per leg     */
   double tau_min, tau_max; /* commander_node.cpp:324-325 */
   double jc_kff[3], jc_kp[3], jc_kd[3]; /* swing-leg joint PD gains, commander_node.cpp:314-341 */
+  double planner_hip[12], planner_k, swing_height; /* foot_planner.cpp:25-42, gait/height commander_node.cpp:247 */
+  double t_swing, t_stance;                        /* gait/t_swing, gait/t_stance, commander_node.cpp:245-246 */
 } oracle_kinematics;
 void oracle_default_kinematics(oracle_kinematics* k);
 /* forwardKinematics(leg, q), kinematics.cpp:81-103 */
@@ -104,6 +106,27 @@ void oracle_tick_swing_batch(const oracle_params* P, const oracle_kinematics* K,
                              const double* x_d, const double* xdot_d, const double* w_d, const double* joint_q,
                              const double* joint_qdot, const double* swing_pos, const double* swing_vel,
                              const unsigned char* stance, double* grf_body, double* joint_tau, int* status, int threads);
+
+/* FootPlanner::state_map_ + FootTrajectoryManager::traj_map_ of one robot (same layout as qc_swing_state). */
+typedef struct oracle_swing_state {
+  int leg_state[4]; /* -1 = state_map_ empty */
+  int has_traj[4];
+  double p_start[12], p_final[12];
+} oracle_swing_state;
+/* One tick of the reference's swing-reference generation, commander_node.cpp:432-471 + 485-489:
+ * foot planner (foot_planner.cpp:46-157), trajectory manager and sextic trajectory (trajectory.cpp:220-388).
+ * feet_body = foot_actual_map; phase[4] = per-leg gait phases; outputs world-frame pos/vel [12]
+ * (zeros for stance legs and for swing legs without a trajectory). */
+void oracle_swing_references(const oracle_kinematics* K, oracle_swing_state* st, const double* Rwb, const double* x,
+                             const double* xdot, const double* w, const double* xdot_d, const double* feet_body,
+                             const unsigned char* stance, const double* phase, double* pos, double* vel);
+/* Full tick with on-the-fly swing references: stance from the gait rule, FK, planner/trajectories,
+ * control(), J^T torques for stance legs, IK/J^-1/PD torques for swing legs. */
+void oracle_tick_planned_batch(const oracle_params* P, const oracle_kinematics* K, long n, oracle_swing_state* states,
+                               const double* Rwb, const double* Rwb_d, const double* x, const double* xdot,
+                               const double* w, const double* x_d, const double* xdot_d, const double* w_d,
+                               const double* joint_q, const double* joint_qdot, const double* gait_phase,
+                               double* grf_body, double* joint_tau, int* status, int threads);
 
 #ifdef __cplusplus
 }

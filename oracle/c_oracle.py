@@ -21,7 +21,13 @@ class OracleParams(C.Structure):
 
 class OracleKinematics(C.Structure):
     _fields_ = [("hip", C.c_double * 12), ("links", C.c_double * 12), ("tau_min", C.c_double), ("tau_max", C.c_double),
-                ("jc_kff", C.c_double * 3), ("jc_kp", C.c_double * 3), ("jc_kd", C.c_double * 3)]
+                ("jc_kff", C.c_double * 3), ("jc_kp", C.c_double * 3), ("jc_kd", C.c_double * 3),
+                ("planner_hip", C.c_double * 12), ("planner_k", C.c_double), ("swing_height", C.c_double),
+                ("t_swing", C.c_double), ("t_stance", C.c_double)]
+
+
+class OracleSwingState(C.Structure):
+    _fields_ = [("leg_state", C.c_int * 4), ("has_traj", C.c_int * 4), ("p_start", C.c_double * 12), ("p_final", C.c_double * 12)]
 
 
 def build(force=False):
@@ -158,4 +164,27 @@ def tick_swing_batch(P, batch, kin=None, threads=1, max_iter=200):
     lib().oracle_tick_swing_batch(C.byref(p), C.byref(kin), C.c_long(n), *[_dp(v) for v in a],
                                   st.ctypes.data_as(C.POINTER(C.c_ubyte)), _dp(grf), _dp(tau),
                                   status.ctypes.data_as(C.POINTER(C.c_int)), C.c_int(threads))
+    return dict(grf_body=grf, joint_tau=tau, status=status)
+
+
+SWING_STATE_DTYPE = np.dtype([("leg_state", np.int32, 4), ("has_traj", np.int32, 4), ("p_start", np.float64, 12), ("p_final", np.float64, 12)])
+
+
+def new_swing_states(n):
+    s = np.zeros(n, dtype=SWING_STATE_DTYPE)
+    s["leg_state"] = -1
+    return s
+
+
+def tick_planned_batch(P, batch, states, kin=None, threads=1, max_iter=200):
+    """Full tick with on-device-style swing planning; `states` (SWING_STATE_DTYPE array) is updated in place."""
+    kin = kin or default_kinematics()
+    p = make_params(P, max_iter)
+    n = batch["x"].shape[0]
+    names = ("Rwb", "Rwb_d", "x", "xdot", "w", "x_d", "xdot_d", "w_d", "joint_q", "joint_qdot", "gait_phase")
+    a = [np.ascontiguousarray(batch[k], np.float64) for k in names]
+    grf = np.zeros((n, 12)); tau = np.zeros((n, 12)); status = np.zeros(n, np.int32)
+    assert states.dtype == SWING_STATE_DTYPE and states.flags["C_CONTIGUOUS"] and C.sizeof(OracleSwingState) == SWING_STATE_DTYPE.itemsize
+    lib().oracle_tick_planned_batch(C.byref(p), C.byref(kin), C.c_long(n), states.ctypes.data_as(C.c_void_p), *[_dp(v) for v in a],
+                                    _dp(grf), _dp(tau), status.ctypes.data_as(C.POINTER(C.c_int)), C.c_int(threads))
     return dict(grf_body=grf, joint_tau=tau, status=status)

@@ -22,7 +22,7 @@ def cheetah_params(mu=0.8):
 
 
 def __getattr__(name):
-    if name in ("BalanceController", "to_device"):
+    if name in ("BalanceController", "to_device", "new_swing_states", "SWING_STATE_DTYPE"):
         from . import balance_controller as _bc
 
         return getattr(_bc, name)

@@ -27,7 +27,7 @@ class QcParams(C.Structure):
 class QcBatchIn(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in
                 ("Rwb", "Rwb_d", "x", "xdot", "w", "x_d", "xdot_d", "w_d", "feet", "stance", "joint_q", "gait_phase", "gait_duty",
-                 "swing_pos", "swing_vel", "joint_qdot")]
+                 "swing_pos", "swing_vel", "joint_qdot", "swing_state")]
 
 
 class QcBatchOut(C.Structure):
@@ -36,11 +36,16 @@ class QcBatchOut(C.Structure):
 
 class QcKinematics(C.Structure):
     _fields_ = [("hip", C.c_double * 12), ("links", C.c_double * 12), ("tau_min", C.c_double), ("tau_max", C.c_double),
-                ("jc_kff", C.c_double * 3), ("jc_kp", C.c_double * 3), ("jc_kd", C.c_double * 3)]
+                ("jc_kff", C.c_double * 3), ("jc_kp", C.c_double * 3), ("jc_kd", C.c_double * 3),
+                ("planner_hip", C.c_double * 12), ("planner_k", C.c_double), ("swing_height", C.c_double)]
+
+
+class QcSwingState(C.Structure):
+    _fields_ = [("leg_state", C.c_int32 * 4), ("has_traj", C.c_int32 * 4), ("p_start", C.c_double * 12), ("p_final", C.c_double * 12)]
 
 
 EXPORTS = ("qc_create", "qc_destroy", "qc_control_batch", "qc_control_batch_host", "qc_control",
-           "qc_last_error", "qc_kernel_name", "qc_abi_version", "qc_default_kinematics", "qc_set_kinematics", "qc_set_gait")
+           "qc_last_error", "qc_kernel_name", "qc_abi_version", "qc_default_kinematics", "qc_set_kinematics", "qc_set_gait", "qc_swing_state_init")
 
 _lib = None
 
@@ -91,6 +96,8 @@ def load():
     lib.qc_set_kinematics.restype = C.c_int
     lib.qc_set_gait.argtypes = [C.c_void_p, C.c_double, C.c_double]
     lib.qc_set_gait.restype = C.c_int
+    lib.qc_swing_state_init.argtypes = [C.c_void_p, C.c_size_t]
+    lib.qc_swing_state_init.restype = None
     _lib = lib
     return lib
 

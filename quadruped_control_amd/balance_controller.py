@@ -61,7 +61,8 @@ class BalanceController:
         return cls(P["mu"], P["mass"], P["fzmin"], P["fzmax"], P["Ib"], P["S"], P["W"], P["kff"],
                    P["kp_p"], P["kd_p"], P["kp_w"], P["kd_w"], **kw)
 
-    def set_kinematics(self, hip=None, links=None, tau_min=None, tau_max=None, jc_kff=None, jc_kp=None, jc_kd=None):
+    def set_kinematics(self, hip=None, links=None, tau_min=None, tau_max=None, jc_kff=None, jc_kp=None, jc_kd=None,
+                       planner_hip=None, planner_k=None, swing_height=None):
         """Kinematic model of the joint_q / joint_tau extension; unspecified parts keep
         the reference's constants (kinematics.cpp:20-47, commander_node.cpp:324-325)."""
         k = _lib.QcKinematics()
@@ -77,6 +78,12 @@ class BalanceController:
         for name, val in (("jc_kff", jc_kff), ("jc_kp", jc_kp), ("jc_kd", jc_kd)):  # swing-leg joint PD gains
             if val is not None:
                 _fill(getattr(k, name), val, 3, name)
+        if planner_hip is not None:
+            _fill(k.planner_hip, planner_hip, 12, "planner_hip")
+        if planner_k is not None:
+            k.planner_k = float(planner_k)
+        if swing_height is not None:
+            k.swing_height = float(swing_height)
         rc = self._lib.qc_set_kinematics(self._h, C.byref(k))
         if rc != _lib.QC_OK:
             raise RuntimeError(f"qc_set_kinematics failed ({rc}): {_lib.last_error()}")
@@ -166,6 +173,11 @@ class BalanceController:
                 if t.dtype != torch.float64 or not t.is_contiguous() or t.numel() != n * k or t.device != dev:
                     raise ValueError(f"{name}: need contiguous float64 [{n},{k}] on {dev}")
                 setattr(bi, name, t.data_ptr())
+        ss = batch.get("swing_state")
+        if ss is not None:  # torch.uint8 tensor of n * sizeof(qc_swing_state) bytes, updated in place
+            if ss.dtype != torch.uint8 or not ss.is_contiguous() or ss.numel() != n * SWING_STATE_DTYPE.itemsize or ss.device != dev:
+                raise ValueError("swing_state: need a contiguous uint8 tensor of n * 224 bytes on the device")
+            bi.swing_state = ss.data_ptr()
         if out is None:
             out = {"grf_body": torch.empty((n, 12), dtype=torch.float64, device=dev),
                    "status": torch.empty((n,), dtype=torch.int32, device=dev)}
@@ -208,7 +220,7 @@ class BalanceController:
         for name, _ in _IN_FIELDS + (("joint_q", 12),):
             if batch.get(name) is not None:
                 setattr(bi, name, batch[name].data_ptr())
-        for name in ("stance", "gait_phase", "gait_duty", "swing_pos", "swing_vel", "joint_qdot"):
+        for name in ("stance", "gait_phase", "gait_duty", "swing_pos", "swing_vel", "joint_qdot", "swing_state"):
             if batch.get(name) is not None:
                 setattr(bi, name, batch[name].data_ptr())
         bo = _lib.QcBatchOut()
@@ -249,6 +261,11 @@ class BalanceController:
             st = np.ascontiguousarray(st, dtype=np.uint8)
             keep.append(st)
             bi.stance = st.ctypes.data
+        ss = batch.get("swing_state")
+        if ss is not None:  # in/out: updated in place
+            if ss.dtype != SWING_STATE_DTYPE or not ss.flags["C_CONTIGUOUS"] or ss.shape != (n,):
+                raise ValueError("swing_state: need a C-contiguous new_swing_states(n) array")
+            bi.swing_state = ss.ctypes.data
         for name in ("gait_phase", "gait_duty", "swing_pos", "swing_vel", "joint_qdot"):
             if batch.get(name) is not None:
                 a = np.ascontiguousarray(batch[name], dtype=np.float64)
@@ -275,6 +292,17 @@ class BalanceController:
         if rc != _lib.QC_OK:
             raise RuntimeError(f"qc_control_batch_host failed ({rc}): {_lib.last_error()}")
         return out
+
+
+SWING_STATE_DTYPE = np.dtype([("leg_state", np.int32, 4), ("has_traj", np.int32, 4),
+                              ("p_start", np.float64, 12), ("p_final", np.float64, 12)])  # == qc_swing_state
+
+
+def new_swing_states(n):
+    """Host array of n `qc_swing_state` records in the "nothing planned yet" state (qc_swing_state_init)."""
+    s = np.zeros(n, dtype=SWING_STATE_DTYPE)
+    _lib.load().qc_swing_state_init(s.ctypes.data_as(C.c_void_p), n)
+    return s
 
 
 def to_device(batch, device=0):

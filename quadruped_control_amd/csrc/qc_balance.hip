@@ -12,6 +12,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <utility>
 
 #include "../../include/qc_balance.h"
 #include "qc_device.hpp"
@@ -219,6 +220,50 @@ struct Lane {
 // per lane) rotates them to the body frame, applies J^T and stores.
 // Stock planes are [field][64 slots] doubles: the dense side touches
 // plane[field][lane] (conflict-free), the group side one slot per group.
+// Swing-planning state update of one robot at the start of its tick, commander_node.cpp:432-471:
+// FootPlanner::updateStates (foot_planner.cpp:106-157) decides which legs need a new foothold (stance ->
+// swing edge, or any swinging leg on the very first call); if there is one, FootTrajectoryManager::
+// referenceStates(gait_map, bounds) (trajectory.cpp:308-344) CLEARS every stored trajectory and creates
+// those of the planned legs from p_start = Rwb foot + x (commander_node.cpp:456) and the planned foothold.
+template <int FPL>
+QC_DEV void swing_plan(CParams& P, const BatchIn& in, long robot, int foot0, uint32_t stance) {
+  constexpr int GG = 4 / FPL;
+  SwingState* S = in.swing_state + robot;
+  const bool first = S->leg_state[0] < 0;  // state_map_.empty()
+  int plan = 0;
+  int prev[FPL], had[FPL];
+#pragma unroll
+  for (int i = 0; i < FPL; i++) {
+    prev[i] = S->leg_state[foot0 + i];
+    had[i] = S->has_traj[foot0 + i];
+    const bool swing_now = !((stance >> (foot0 + i)) & 1u);
+    if (swing_now && (first || prev[i] == 1)) plan |= 1 << i;
+  }
+  const bool any = group_or<GG>(plan) != 0;
+  double R[9], x[3], xdot[3], w[3], xdot_d[3];
+  load9(in.Rwb, robot, R);
+  load3(in.x, robot, x);
+  load3(in.xdot, robot, xdot);
+  load3(in.w, robot, w);
+  load3(in.xdot_d, robot, xdot_d);
+#pragma unroll
+  for (int i = 0; i < FPL; i++) {
+    const int leg = foot0 + i;
+    if ((plan >> i) & 1) {
+      double pb[3], fh[3];
+      leg_fk(P, leg, leg_trig(in.joint_q + 12 * robot + 3 * leg), pb);  // foot_actual_map, commander_node.cpp:383-384
+      plan_foothold(P, leg, R, x, xdot, w, xdot_d, pb, fh);
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        S->p_start[3 * leg + r] = R[3 * r] * pb[0] + R[3 * r + 1] * pb[1] + R[3 * r + 2] * pb[2] + x[r];  // :456
+        S->p_final[3 * leg + r] = fh[r];
+      }
+    }
+    S->has_traj[leg] = any ? ((plan >> i) & 1) : had[i];
+    S->leg_state[leg] = ((stance >> leg) & 1u) ? 1 : 0;
+  }
+}
+
 // FPL = 4: one lane assembles a whole robot (dense restock of a big batch);
 // FPL = 4/G: the G lanes of a group share a robot, each doing its own feet
 // (small fills, where latency matters more than lane efficiency).
@@ -245,6 +290,7 @@ QC_DEV void assemble_to_stock(CParams& P, const BatchIn& in, const uint32_t* __r
       stance |= (ge0 && le) ? (1u << i) : 0u;
     }
   }
+  if (KIN && in.swing_state) swing_plan<FPL>(P, in, robot, foot0, stance);
   const uint32_t wv = warm ? warm[robot] : 0u;
   // non-finite inputs poison b, r or R: report QC_NOT_PD instead of iterating on NaNs
   const bool bad = group_or<GG>(!(fin == 0.0) ? 1 : 0) != 0;
@@ -293,9 +339,27 @@ QC_DEV void store_from_stock(CParams& P, const BatchIn& in, const BatchOut& out,
       const double* qp = in.joint_q + 12 * idx + 3 * (foot0 + i);
       double tau[3];
       bool emit = st;
-      if (in.swing_pos && !stance_leg) {  // swing leg: IK + J^-1 + joint PD, commander_node.cpp:482-504
-        const double* sp = in.swing_pos + 12 * idx + 3 * (foot0 + i);
-        const double* sv = in.swing_vel + 12 * idx + 3 * (foot0 + i);
+      if ((in.swing_pos || in.swing_state) && !stance_leg) {  // swing leg: IK + J^-1 + joint PD, commander_node.cpp:482-504
+        double sp[3], sv[3];
+        if (in.swing_state) {  // FootTrajectoryManager::referenceState(leg, phase), trajectory.cpp:360-388
+          const SwingState* S = in.swing_state + idx;
+          // written by this wave's assembly phase: read past the (possibly stale) vector L1
+          const int has = __hip_atomic_load(&S->has_traj[foot0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          double p0[3], pf[3];
+#pragma unroll
+          for (int r = 0; r < 3; r++) {
+            p0[r] = __hip_atomic_load(&S->p_start[3 * (foot0 + i) + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pf[r] = __hip_atomic_load(&S->p_final[3 * (foot0 + i) + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          track_swing(P, in.gait_phase[4 * idx + foot0 + i], p0, pf, sp, sv);
+          if (!has) sp[0] = sp[1] = sp[2] = sv[0] = sv[1] = sv[2] = 0.0;  // no trajectory: FootState() (:387)
+        } else {
+#pragma unroll
+          for (int r = 0; r < 3; r++) {
+            sp[r] = in.swing_pos[12 * idx + 3 * (foot0 + i) + r];
+            sv[r] = in.swing_vel[12 * idx + 3 * (foot0 + i) + r];
+          }
+        }
         const double* xp = in.x + 3 * idx;
         double pb[3], vb[3];
 #pragma unroll
@@ -492,6 +556,32 @@ static bool spd_inverse(const double* A, int n, double* inv) {
   return true;
 }
 
+// Columns 0..2 of the inverse of FootTrajectory::initSystem()'s 7x7 matrix (trajectory.cpp:256-277):
+// the responses of the sextic coefficients to p_start, p_final and p_centre.  basis[3*j + k].
+static void sextic_basis(double* basis) {
+  double A[7][7] = {{1, 0, 0, 0, 0, 0, 0}, {1, 1, 1, 1, 1, 1, 1}, {1, 0.5, 0.25, 0.125, 0.0625, 0.03125, 0.015625},
+                    {0, 1, 0, 0, 0, 0, 0}, {0, 1, 2, 3, 4, 5, 6}, {0, 0, 2, 0, 0, 0, 0}, {0, 0, 2, 6, 12, 20, 30}};
+  double M[7][10];
+  for (int i = 0; i < 7; i++) {
+    for (int j = 0; j < 7; j++) M[i][j] = A[i][j];
+    for (int k = 0; k < 3; k++) M[i][7 + k] = (i == k) ? 1.0 : 0.0;
+  }
+  for (int c = 0; c < 7; c++) {
+    int p = c;
+    for (int r = c + 1; r < 7; r++) if (std::fabs(M[r][c]) > std::fabs(M[p][c])) p = r;
+    for (int j = 0; j < 10; j++) std::swap(M[c][j], M[p][j]);
+    const double piv = M[c][c];
+    for (int j = 0; j < 10; j++) M[c][j] /= piv;
+    for (int r = 0; r < 7; r++) {
+      if (r == c) continue;
+      const double m = M[r][c];
+      for (int j = 0; j < 10; j++) M[r][j] -= m * M[c][j];
+    }
+  }
+  for (int j = 0; j < 7; j++)
+    for (int k = 0; k < 3; k++) basis[3 * j + k] = M[j][7 + k];
+}
+
 extern "C" {
 
 const char* qc_last_error(void) { return g_err.c_str(); }
@@ -515,6 +605,18 @@ void qc_default_kinematics(qc_kinematics* k) {
   std::memcpy(k->jc_kff, kff, sizeof(kff));
   std::memcpy(k->jc_kp, kp, sizeof(kp));
   std::memcpy(k->jc_kd, kd, sizeof(kd));
+  const double xbt = 0.196, ybt = 0.127, zbt = 0.0;  // foot_planner.cpp:27-42
+  const double phip[12] = {-xbt, ybt, zbt, xbt, ybt, zbt, -xbt, -ybt, zbt, xbt, -ybt, zbt};
+  std::memcpy(k->planner_hip, phip, sizeof(phip));
+  k->planner_k = 0.01;     // foot_planner.cpp:25
+  k->swing_height = 0.08;  // gait/height, commander_node.cpp:247
+}
+
+void qc_swing_state_init(qc_swing_state* s, size_t n) {
+  if (!s) return;
+  std::memset(s, 0, n * sizeof(qc_swing_state));
+  for (size_t i = 0; i < n; i++)
+    for (int l = 0; l < 4; l++) s[i].leg_state[l] = -1;
 }
 
 int qc_set_kinematics(qc_handle* h, const qc_kinematics* kin) {
@@ -529,6 +631,9 @@ int qc_set_kinematics(qc_handle* h, const qc_kinematics* kin) {
   std::memcpy(h->dp.jc_kff, k.jc_kff, sizeof(k.jc_kff));
   std::memcpy(h->dp.jc_kp, k.jc_kp, sizeof(k.jc_kp));
   std::memcpy(h->dp.jc_kd, k.jc_kd, sizeof(k.jc_kd));
+  std::memcpy(h->dp.planner_hip, k.planner_hip, sizeof(k.planner_hip));
+  h->dp.planner_k = k.planner_k;
+  h->dp.swing_height = k.swing_height;
   QC_HIP(hipSetDevice(h->device));
   QC_HIP(hipMemcpy(h->d_params, &h->dp, sizeof(qc::DevParams), hipMemcpyHostToDevice));  // synchronous: no launch races it
   return QC_OK;
@@ -538,6 +643,8 @@ int qc_set_gait(qc_handle* h, double t_swing, double t_stance) {
   if (!h) return fail(QC_ERR_INVALID, "qc_set_gait: null handle");
   if (!(t_swing >= 0.0) || !(t_stance >= 0.0) || !(t_swing + t_stance > 0.0)) return fail(QC_ERR_INVALID, "qc_set_gait: need t_swing, t_stance >= 0, not both 0");
   h->dp.stance_phase = t_stance / (t_swing + t_stance);  // gait.cpp:45
+  h->dp.t_swing = t_swing;
+  h->dp.t_stance = t_stance;
   QC_HIP(hipSetDevice(h->device));
   QC_HIP(hipMemcpy(h->d_params, &h->dp, sizeof(qc::DevParams), hipMemcpyHostToDevice));
   return QC_OK;
@@ -618,6 +725,12 @@ int qc_create(const qc_params* p, int device, qc_handle** out) {
     std::memcpy(d.jc_kff, k.jc_kff, sizeof(k.jc_kff));
     std::memcpy(d.jc_kp, k.jc_kp, sizeof(k.jc_kp));
     std::memcpy(d.jc_kd, k.jc_kd, sizeof(k.jc_kd));
+    std::memcpy(d.planner_hip, k.planner_hip, sizeof(k.planner_hip));
+    d.planner_k = k.planner_k;
+    d.swing_height = k.swing_height;
+    d.t_swing = 0.18;  // mit_cheetah_config.yaml:17-18
+    d.t_stance = 0.8;
+    sextic_basis(d.traj_basis);
   }
   d.stance_phase = 0.8 / (0.18 + 0.8);  // mit_cheetah_config.yaml:17-18
   d.tol_d = 1e-12;  // relative to 1+|grad|_inf: W ~ 1e-5 makes the primal very sensitive to a wrongly kept weakly-active face
@@ -661,10 +774,13 @@ int qc_control_batch(qc_handle* h, size_t n, const qc_batch_in* in, const uint32
   QC_HIP(hipSetDevice(h->device));
   const bool kin = in->joint_q != nullptr;
   const int n_sw = (in->swing_pos ? 1 : 0) + (in->swing_vel ? 1 : 0) + (in->joint_qdot ? 1 : 0);
-  if (n_sw != 0 && (n_sw != 3 || !in->joint_q || !out->joint_tau))
+  if (!in->swing_state && n_sw != 0 && (n_sw != 3 || !in->joint_q || !out->joint_tau))
     return fail(QC_ERR_INVALID, "qc_control_batch: swing_pos, swing_vel and joint_qdot go together and need joint_q and joint_tau");
+  if (in->swing_state && (!in->joint_q || !in->joint_qdot || !in->gait_phase || !out->joint_tau || in->swing_pos || in->swing_vel))
+    return fail(QC_ERR_INVALID, "qc_control_batch: swing_state needs joint_q, joint_qdot, gait_phase and joint_tau, and excludes swing_pos/swing_vel");
   qc::BatchIn bi{in->Rwb, in->Rwb_d, in->x, in->xdot, in->w, in->x_d, in->xdot_d, in->w_d, in->feet, in->stance, in->joint_q,
-                 in->gait_phase, in->gait_duty, in->swing_pos, in->swing_vel, in->joint_qdot};
+                 in->gait_phase, in->gait_duty, in->swing_pos, in->swing_vel, in->joint_qdot,
+                 reinterpret_cast<qc::SwingState*>(in->swing_state)};
   qc::BatchOut bo{out->grf_body, out->status, out->active_set, out->iterations, out->joint_tau};
   // One wave per 64-thread block; a group of G lanes per robot.  The group
   // width trades latency for throughput: G = 4 (foot per lane) cuts the serial
@@ -717,7 +833,7 @@ int qc_control_batch_host(qc_handle* h, size_t n, const qc_batch_in* in, const u
   QC_HIP(hipSetDevice(h->device));
   if (!h->stream) QC_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   // layout (all 8-byte aligned): 48 doubles in, 12 doubles out, 4 x 4-byte words
-  const size_t per = 48 * 8 + 12 * 8 + 4 * 4 + 8 + 12 * 8 + 12 * 8 + 5 * 8 + 3 * 12 * 8;
+  const size_t per = 48 * 8 + 12 * 8 + 4 * 4 + 8 + 12 * 8 + 12 * 8 + 5 * 8 + 3 * 12 * 8 + sizeof(qc_swing_state);
   const size_t need = n * per + 256;
   if (need > h->stage_bytes) {
     if (h->stage) QC_HIP(hipFree(h->stage));
@@ -769,12 +885,17 @@ int qc_control_batch_host(qc_handle* h, size_t n, const qc_batch_in* in, const u
     d_warm = (uint32_t*)carve(n * 4);
     QC_HIP(hipMemcpyAsync(d_warm, warm, n * 4, hipMemcpyHostToDevice, h->stream));
   }
+  qc_swing_state* d_ss = nullptr;
+  if (in->swing_state) {
+    d_ss = (qc_swing_state*)carve(n * sizeof(qc_swing_state));
+    QC_HIP(hipMemcpyAsync(d_ss, in->swing_state, n * sizeof(qc_swing_state), hipMemcpyHostToDevice, h->stream));
+  }
   double* d_grf = (double*)carve(n * 12 * 8);
   int32_t* d_status = (int32_t*)carve(n * 4);
   uint32_t* d_act = out->active_set ? (uint32_t*)carve(n * 4) : nullptr;
   int32_t* d_it = out->iterations ? (int32_t*)carve(n * 4) : nullptr;
   if (off > h->stage_bytes) return fail(QC_ERR_INVALID, "qc_control_batch_host: staging overflow");
-  qc_batch_in din{dptr[0], dptr[1], dptr[2], dptr[3], dptr[4], dptr[5], dptr[6], dptr[7], dptr[8], d_st, d_q, d_gp, d_gd, d_sw[0], d_sw[1], d_sw[2]};
+  qc_batch_in din{dptr[0], dptr[1], dptr[2], dptr[3], dptr[4], dptr[5], dptr[6], dptr[7], dptr[8], d_st, d_q, d_gp, d_gd, d_sw[0], d_sw[1], d_sw[2], d_ss};
   qc_batch_out dout{d_grf, d_status, d_act, d_it, d_tau};
   int rc = qc_control_batch(h, n, &din, d_warm, &dout, h->stream);
   if (rc != QC_OK) return rc;
@@ -783,6 +904,7 @@ int qc_control_batch_host(qc_handle* h, size_t n, const qc_batch_in* in, const u
   if (d_act) QC_HIP(hipMemcpyAsync(out->active_set, d_act, n * 4, hipMemcpyDeviceToHost, h->stream));
   if (d_it) QC_HIP(hipMemcpyAsync(out->iterations, d_it, n * 4, hipMemcpyDeviceToHost, h->stream));
   if (d_tau) QC_HIP(hipMemcpyAsync(out->joint_tau, d_tau, n * 12 * 8, hipMemcpyDeviceToHost, h->stream));
+  if (d_ss) QC_HIP(hipMemcpyAsync(in->swing_state, d_ss, n * sizeof(qc_swing_state), hipMemcpyDeviceToHost, h->stream));
   QC_HIP(hipStreamSynchronize(h->stream));
   return QC_OK;
 }
@@ -790,7 +912,7 @@ int qc_control_batch_host(qc_handle* h, size_t n, const qc_batch_in* in, const u
 int qc_control(qc_handle* h, const double* Rwb, const double* Rwb_d, const double* x, const double* xdot,
                const double* w, const double* x_d, const double* xdot_d, const double* w_d, const double* feet,
                const uint8_t* stance, double* grf_body, int32_t* status) {
-  qc_batch_in in{Rwb, Rwb_d, x, xdot, w, x_d, xdot_d, w_d, feet, stance, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  qc_batch_in in{Rwb, Rwb_d, x, xdot, w, x_d, xdot_d, w_d, feet, stance, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   qc_batch_out out{grf_body, status, nullptr, nullptr, nullptr};
   return qc_control_batch_host(h, 1, &in, nullptr, &out);
 }

@@ -46,6 +46,9 @@ struct DevParams {
   double links[12];    // [leg][l1,l2,l3] signed
   double tau_min, tau_max;
   double jc_kff[3], jc_kp[3], jc_kd[3];  // swing-leg joint PD (joint_controller.cpp)
+  // swing reference generator (foot_planner.cpp, trajectory.cpp)
+  double planner_hip[12], planner_k, swing_height, t_swing, t_stance;
+  double traj_basis[21];  // [power j][k]: column k of A^-1 of the sextic system (trajectory.cpp:256-277), k = start, final, centre
   double stance_phase; // gait.cpp:45, default duty of the on-device contact rule
   double tol_d;        // relative multiplier tolerance
   int max_iter;
@@ -65,6 +68,14 @@ typedef const __attribute__((address_space(4))) DevParams CParams;
     (CParams*)(unsigned long long)p_;      \
   })
 
+// mirrors qc_swing_state (include/qc_balance.h)
+struct SwingState {
+  int32_t leg_state[4];
+  int32_t has_traj[4];
+  double p_start[12];
+  double p_final[12];
+};
+
 struct BatchIn {
   const double *Rwb, *Rwb_d, *x, *xdot, *w, *x_d, *xdot_d, *w_d, *feet;
   const uint8_t* stance;
@@ -74,6 +85,7 @@ struct BatchIn {
   const double* swing_pos;
   const double* swing_vel;
   const double* joint_qdot;
+  struct SwingState* swing_state;
 };
 struct BatchOut {
   double* grf_body;
@@ -269,15 +281,19 @@ QC_DEV void leg_swing_torque(CParams& P, int leg, const double (&pb)[3], const d
   qr[0] = right ? atan2(z, y) + atan2(rt, -l1) : -(atan2(z, -y) + atan2(rt, -l1));
   qr[2] = atan2(-sqrt(1.0 - d * d), d);
   qr[1] = -atan2(x, rt) - atan2(l3 * sin(qr[2]), l2 + l3 * cos(qr[2]));
-  // legJacobianInverse(q_ref) * vb, kinematics.cpp:190-204 (closed-form inverse; J^T if exactly singular)
+  // legJacobianInverse(q_ref) * vb, kinematics.cpp:190-204 (closed-form inverse; J^T if singular)
   const LegTrig t = leg_trig(qr);
   const double L1 = P.links[3 * leg], L2 = P.links[3 * leg + 1], L3 = P.links[3 * leg + 2];
   const double a = L2 * t.c2 + L3 * t.c23, b = L2 * t.s2 + L3 * t.s23;
   const double J[9] = {0.0, a, L3 * t.c23, -L1 * t.s1 - a * t.c1, b * t.s1, L3 * t.s1 * t.s23, L1 * t.c1 - a * t.s1, -b * t.c1, -L3 * t.s23 * t.c1};
   const double c00 = J[4] * J[8] - J[5] * J[7], c01 = J[5] * J[6] - J[3] * J[8], c02 = J[3] * J[7] - J[4] * J[6];
   const double det = J[0] * c00 + J[1] * c01 + J[2] * c02;
+  // A (numerically) singular J - leg fully stretched because the reference point is out of reach, where IK
+  // clamps d to 1 - makes arma::inv's answer in the reference a LAPACK-dependent garbage value; here, as in
+  // the oracle, |det| <= 1e-9 (|l1|+|l2|+|l3|)^3 takes the reference's last-resort branch J^T (kinematics.cpp:198).
+  const double lsum = fabs(L1) + fabs(L2) + fabs(L3);
   double qd[3];
-  if (det != 0.0) {
+  if (fabs(det) > 1.0e-9 * lsum * lsum * lsum) {
     const double id = 1.0 / det;
     // inverse = adj / det; row r of the inverse dotted with vb
     qd[0] = id * (c00 * vb[0] + (J[2] * J[7] - J[1] * J[8]) * vb[1] + (J[1] * J[5] - J[2] * J[4]) * vb[2]);
@@ -292,6 +308,49 @@ QC_DEV void leg_swing_torque(CParams& P, int leg, const double (&pb)[3], const d
   for (int c = 0; c < 3; c++) {
     const double e = normalize_angle_PI(normalize_angle_2PI(qr[c]) - normalize_angle_2PI(q[c]));
     tau[c] = P.jc_kp[c] * e + P.jc_kd[c] * (qd[c] - qdot[c]) + P.jc_kff[c];
+  }
+}
+
+// ---- swing reference generator ----------------------------------------------
+// FootPlanner::singleFoot, foot_planner.cpp:76-104 (world-frame foothold of one leg)
+QC_DEV void plan_foothold(CParams& P, int leg, const double (&R)[9], const double (&x)[3], const double (&xdot)[3], const double (&w)[3],
+                          const double (&xdot_d)[3], const double (&foot_b)[3], double (&fh)[3]) {
+  double pt[3], pc[3];
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    pt[r] = R[3 * r] * P.planner_hip[3 * leg] + R[3 * r + 1] * P.planner_hip[3 * leg + 1] + R[3 * r + 2] * P.planner_hip[3 * leg + 2] + x[r];
+    pc[r] = R[3 * r] * foot_b[0] + R[3 * r + 1] * foot_b[1] + R[3 * r + 2] * foot_b[2];
+  }
+  const double tv[3] = {w[1] * pc[2] - w[2] * pc[1], w[2] * pc[0] - w[0] * pc[2], w[0] * pc[1] - w[1] * pc[0]};
+  const double half = 0.5 * P.t_stance, lip = 0.5 * sqrt(x[2] / 9.81);
+#pragma unroll
+  for (int r = 0; r < 3; r++) fh[r] = pt[r] + (half * xdot[r] + P.planner_k * (xdot[r] - xdot_d[r])) + half * tv[r] + lip * xdot[r];
+  fh[2] = 0.0;
+}
+// FootTrajectoryManager::referenceState + FootTrajectory::trackTrajectory, trajectory.cpp:234-254, 360-388.
+// coefficients = A^-1 B with B = [p_start; p_final; p_centre; 0...] (trajectory.cpp:220-225, 279-296), so
+// s(t) = h0(t) p_start + h1(t) p_final + h2(t) p_centre with h_k(t) = sum_j basis[j][k] t^j.
+QC_DEV void track_swing(CParams& P, double phase, const double (&p0)[3], const double (&pf)[3], double (&pos)[3], double (&vel)[3]) {
+  const double duty = P.t_stance / (P.t_swing + P.t_stance);  // stance_phase_, trajectory.cpp:303
+  const double slope = 1.0 / (1.0 - duty), yint = 1.0 - slope; // :304-305
+  const double t = fmin(fmax(slope * phase + yint, 0.0), 1.0);  // :369
+  double h[3] = {0.0, 0.0, 0.0}, dh[3] = {0.0, 0.0, 0.0};
+  double tp = 1.0, tpm = 0.0;  // t^j and j t^(j-1)
+#pragma unroll
+  for (int j = 0; j < 7; j++) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      h[k] = __builtin_fma(P.traj_basis[3 * j + k], tp, h[k]);
+      dh[k] = __builtin_fma(P.traj_basis[3 * j + k], tpm, dh[k]);
+    }
+    tpm = (double)(j + 1) * tp;
+    tp *= t;
+  }
+  const double pc[3] = {0.5 * (p0[0] + pf[0]), 0.5 * (p0[1] + pf[1]), P.swing_height};  // trajectory.cpp:325-326
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    pos[r] = h[0] * p0[r] + h[1] * pf[r] + h[2] * pc[r];
+    vel[r] = dh[0] * p0[r] + dh[1] * pf[r] + dh[2] * pc[r];
   }
 }
 

@@ -366,3 +366,27 @@ def test_swing_leg_torques(q, n):
     bad = {k: v for k, v in b.items() if k != "swing_vel"}
     with pytest.raises(RuntimeError, match="go together"):
         ctl.control_batch_host(bad, want_torques=True)
+
+
+@pytest.mark.parametrize("n", [600, 36000])
+def test_on_device_swing_planning_multi_tick(q, n):
+    """SURVEY 8f rank 4, stateful half: foothold planner + sextic swing trajectories kept in a
+    per-robot state buffer across ticks; torques and the carried state track the oracle tick by tick."""
+    from oracle import c_oracle as O
+    from tests.test_oracle_cpu import _planned_batch
+
+    P = q.cheetah_params(0.6)
+    ctl = q.BalanceController.from_params(P)
+    dev_state = q.new_swing_states(n)
+    ref_state = O.new_swing_states(n)
+    for tick in range(0, 200, 8):
+        b = _planned_batch(n, tick)
+        o = ctl.control_batch_host(dict(b, swing_state=dev_state), want_torques=True)
+        ref = O.tick_planned_batch(P, b, ref_state, threads=8)
+        assert (o["status"] == 0).all()
+        assert np.array_equal(dev_state["leg_state"], ref_state["leg_state"]) and np.array_equal(dev_state["has_traj"], ref_state["has_traj"])
+        m = ref_state["has_traj"].repeat(3, axis=1) == 1
+        assert np.max(np.abs(dev_state["p_start"][m] - ref_state["p_start"][m])) < 1e-9
+        assert np.max(np.abs(dev_state["p_final"][m] - ref_state["p_final"][m])) < 1e-9
+        assert np.max(np.abs(o["joint_tau"] - ref["joint_tau"])) < 2e-5, tick
+    assert (ref_state["has_traj"] == 1).any()

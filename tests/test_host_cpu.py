@@ -27,8 +27,9 @@ def test_param_struct_layout_matches_c():
     from quadruped_control_amd import _lib
 
     assert ctypes.sizeof(_lib.QcParams) == 8 * (4 + 9 + 36 + 144 + 6 + 3 * 4) + 8
-    assert ctypes.sizeof(_lib.QcBatchIn) == 16 * 8 and ctypes.sizeof(_lib.QcBatchOut) == 5 * 8
-    assert ctypes.sizeof(_lib.QcKinematics) == 35 * 8
+    assert ctypes.sizeof(_lib.QcBatchIn) == 17 * 8 and ctypes.sizeof(_lib.QcBatchOut) == 5 * 8
+    assert ctypes.sizeof(_lib.QcKinematics) == 49 * 8
+    assert ctypes.sizeof(_lib.QcSwingState) == 224
 
 
 def test_no_gpu_fails_loudly(built):

@@ -191,3 +191,61 @@ def test_swing_torque_composition():
     b0["joint_q"] = np.stack([np.concatenate([O.leg_ik(leg, pb[i, leg]) for leg in range(4)]) for i in range(n)])
     t0 = O.tick_swing_batch(P, b0)
     assert np.max(np.abs(t0["joint_tau"][~st])) < 1e-9
+
+
+def _planned_batch(n, tick, dt=1.0 / 300.0):
+    """config-3-like states with a trot gait clock (offsets 0,.5,.5,0; 0.8/0.18) advanced to `tick`."""
+    b = W.with_joint_angles(W.config3(n))
+    b = W.with_swing_references(b)  # for joint_qdot
+    phi0 = W.uniform(0x5EED0008, np.arange(n, dtype=np.uint64), 7)
+    ph = np.fmod(np.array([0.0, 0.5, 0.5, 0.0])[None] + phi0[:, None] + tick * dt / 0.98, 1.0)
+    out = {k: v for k, v in b.items() if k not in ("stance", "swing_pos", "swing_vel")}
+    out["gait_phase"] = np.ascontiguousarray(ph)
+    return out
+
+
+def test_swing_planner_and_trajectories():
+    P = R.cheetah_params(0.6)
+    n = 64
+    st = O.new_swing_states(n)
+    kin = O.default_kinematics()
+    duty = 0.8 / 0.98
+    saw_replan = False
+    for tick in range(0, 240, 3):
+        b = _planned_batch(n, tick)
+        prev = st.copy()
+        t = O.tick_planned_batch(P, b, st)
+        stance = ((b["gait_phase"] >= 0) & (b["gait_phase"] <= duty + 1e-12)).astype(np.int32)
+        assert np.array_equal(st["leg_state"], stance)
+        # a stance -> swing edge (or a swinging leg on the first call) plans a foothold on the ground plane
+        edge = (stance == 0) & ((prev["leg_state"] == 1) | (prev["leg_state"][:, :1] < 0))
+        if tick > 0 and edge.any():
+            saw_replan = True
+        assert np.all(st["has_traj"][edge] == 1)
+        assert np.all(st["p_final"].reshape(n, 4, 3)[edge][:, 2] == 0.0)
+        # robots without an edge keep their trajectories untouched
+        quiet = ~edge.any(axis=1)
+        assert np.array_equal(st["has_traj"][quiet], prev["has_traj"][quiet])
+        assert np.all(np.abs(t["joint_tau"]) <= 20.0)
+    assert saw_replan
+    # sextic trajectory end conditions through the public reference function (trajectory.cpp:256-277)
+    s1 = O.new_swing_states(1)
+    s1["leg_state"][0] = [1, 1, 1, 1]
+    I, z = np.eye(3).reshape(-1), np.zeros(3)
+    feet = np.array([-0.2, 0.13, -0.26, 0.2, 0.13, -0.26, -0.2, -0.13, -0.26, 0.2, -0.13, -0.26])
+    x = np.array([0.0, 0.0, 0.26])
+    stance = np.array([1, 0, 1, 1], np.uint8)
+    pos = np.zeros(12); vel = np.zeros(12)
+    import ctypes as C
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+    def refs(phase):
+        ph = np.full(4, phase)
+        O.lib().oracle_swing_references(C.byref(kin), s1.ctypes.data_as(C.c_void_p), dp(I), dp(x), dp(z), dp(z), dp(z), dp(feet),
+                                        stance.ctypes.data_as(C.POINTER(C.c_ubyte)), dp(ph), dp(pos), dp(vel))
+        return pos[3:6].copy(), vel[3:6].copy()
+    p0, v0 = refs(duty)            # swing starts: t = 0
+    np.testing.assert_allclose(p0, s1["p_start"][0, 3:6], atol=1e-12); np.testing.assert_allclose(v0, 0.0, atol=1e-10)
+    pm, _ = refs(duty + 0.5 * (1 - duty))
+    assert abs(pm[2] - 0.08) < 1e-12  # apex = gait/height at the middle of the swing
+    pf, vf = refs(1.0)             # t = 1
+    np.testing.assert_allclose(pf, s1["p_final"][0, 3:6], atol=1e-12); np.testing.assert_allclose(vf, 0.0, atol=1e-9)
