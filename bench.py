@@ -90,7 +90,17 @@ def run_config(ctl, q, cfg, n, start, steps, warmup, dist=None, device=0, fused=
         from quadruped_control_amd import workloads as W
 
         batch = W.with_joint_angles(batch, start=start)
+        if fused == "full":  # rows 3+4 too: contact state from gait phases, swing planner/trajectories/IK/PD
+            import numpy as np
+
+            batch = W.with_swing_references(batch, start=start)
+            idx = np.arange(start, start + n, dtype=np.uint64)
+            phase = np.fmod(np.array([0.0, 0.5, 0.5, 0.0])[None] + W.uniform(0x5EED0009, idx, 3)[:, None], 1.0)
+            batch = {k: v for k, v in batch.items() if k not in ("stance", "swing_pos", "swing_vel")}
+            batch["gait_phase"] = np.ascontiguousarray(phase)
     dev_batch = q.to_device(batch, device)
+    if fused == "full":
+        dev_batch["swing_state"] = torch.from_numpy(q.new_swing_states(n).view("uint8").reshape(-1).copy()).to(f"cuda:{device}")
     warm = None
     if prev is not None:  # config 4: tick 0 (cold) produces the warm-start words for tick 1
         o0 = ctl.control_batch(q.to_device(prev, device), want_active_set=True)
@@ -263,6 +273,11 @@ def main():
             other["config2_fused_tick"] = {"robots": CONFIG_N[2], "QPs_per_s": CONFIG_N[2] * max(5, min(args.steps, 50)) / r["wall"],
                                            "solved_fraction": r["solved"] / CONFIG_N[2],
                                            "what": "joint_q -> forward kinematics -> control() -> clamp(J^T f) -> joint_tau in one launch (584 B/robot)"}
+            r = run_config(ctl, q, 3, CONFIG_N[3], 0, max(5, min(args.steps, 50)), 3, None, device, fused="full")
+            other["config3_full_tick"] = {"robots": CONFIG_N[3], "ticks_per_s": CONFIG_N[3] * max(5, min(args.steps, 50)) / r["wall"],
+                                          "solved_fraction": r["solved"] / CONFIG_N[3],
+                                          "what": "joint states + COM state + gait phases -> complete joint torque command "
+                                                  "(FK, contact rule, foothold planner, swing trajectories, IK, joint PD, QP, J^T) in one launch"}
             line["other_configs"] = other
         print(json.dumps(line), flush=True)
 
