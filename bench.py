@@ -187,6 +187,8 @@ def main():
     ap.add_argument("--n", type=int, default=0, help="robots per GPU (default: the config's size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true", help="skip the informational runs of the other configs")
+    ap.add_argument("--probe-batch-load", action="store_true",
+                    help="also time the load -> assemble -> store phase alone (no solver iterations) on 2,097,152 robots")
     args = ap.parse_args()
 
     import torch
@@ -279,6 +281,18 @@ def main():
                                           "what": "joint states + COM state + gait phases -> complete joint torque command "
                                                   "(FK, contact rule, foothold planner, swing trajectories, IK, joint PD, QP, J^T) in one launch"}
             line["other_configs"] = other
+        if world == 1 and args.probe_batch_load:
+            # north_star: "achieved HBM GB/s on the batch load".  Same kernel, solver iterations skipped
+            # (status = max_iter for every robot), batch larger than the 256 MiB Infinity Cache.
+            os.environ["QC_PROBE_BATCH_LOAD"] = "1"
+            probe = q.BalanceController.from_params(P, device=device)
+            del os.environ["QC_PROBE_BATCH_LOAD"]
+            nb = 2097152
+            r = run_config(probe, q, 5, nb, 0, 10, 2, None, device)
+            gbs = BYTES_PER_ROBOT_COLD * nb * 10 / r["event_s"] / 1e9
+            line["batch_load_probe"] = {"robots": nb, "bytes": BYTES_PER_ROBOT_COLD * nb, "us": r["event_s"] / 10 * 1e6,
+                                        "achieved": gbs, "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS,
+                                        "what": "load -> assemble (PD law, rotation log, Newton-Euler rhs) -> output transform -> store, no QP iterations"}
         print(json.dumps(line), flush=True)
 
     if dist is not None:

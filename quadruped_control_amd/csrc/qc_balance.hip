@@ -92,6 +92,7 @@ struct Lane {
   // one working-set recalculation; returns true when the robot is finished
   QC_DEV bool iterate(CParams& P, Eqp& eqp) {
     double fh[3 * FPL], g[3 * FPL];
+    if (P.max_iter == 0) return true;  // measurement probe (QC_PROBE_BATCH_LOAD): load -> assemble -> store only
     iters++;
     const bool pd = eqp.solve(P, Wr, C, stance, foot0, fh, g);
     const bool fresh = !have_f;
@@ -736,6 +737,7 @@ int qc_create(const qc_params* p, int device, qc_handle** out) {
   d.tol_d = 1e-12;  // relative to 1+|grad|_inf: W ~ 1e-5 makes the primal very sensitive to a wrongly kept weakly-active face
   if (const char* e = std::getenv("QC_TOL_D")) d.tol_d = std::atof(e);  // development knob
   d.max_iter = p->max_iter > 0 ? p->max_iter : 200;
+  if (const char* e = std::getenv("QC_PROBE_BATCH_LOAD")) if (e[0] == '1') d.max_iter = 0;  // bench.py --probe-batch-load
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete h; return fail(QC_ERR_HIP, "qc_create: hipGetDeviceProperties failed"); }
   h->wave_slots = prop.multiProcessorCount * 4 * (h->diag_w ? 2 : 1);
