@@ -160,6 +160,31 @@ def cpu_baseline(P, batch, budget_s=4.0):
             "single_thread_value": one}
 
 
+def batch_load_probe(q, P, device, nb=2097152, steps=10):
+    """north_star: "achieved HBM GB/s on the batch load".  Same kernel with the solver iterations skipped
+    (QC_PROBE_BATCH_LOAD: load -> PD law / rotation log / Newton-Euler rhs -> output transform -> store;
+    status = max_iter for every robot) on a batch four times the 256 MiB Infinity Cache.  The rows are
+    262,144 config-5 robots tiled 8x on the device (their values do not matter without iterations)."""
+    import torch
+
+    from quadruped_control_amd import workloads as W
+
+    os.environ["QC_PROBE_BATCH_LOAD"] = "1"
+    try:
+        probe = q.BalanceController.from_params(P, device=device)
+    finally:
+        del os.environ["QC_PROBE_BATCH_LOAD"]
+    base = q.to_device(W.config5(nb // 8), device)
+    batch = {k: v.repeat(8, 1).contiguous() for k, v in base.items()}
+    out = {"grf_body": torch.empty((nb, 12), dtype=torch.float64, device=f"cuda:{device}"),
+           "status": torch.empty((nb,), dtype=torch.int32, device=f"cuda:{device}")}
+    _, evs = time_steps(probe, batch, None, out, steps, 2)
+    gbs = BYTES_PER_ROBOT_COLD * nb * steps / evs / 1e9
+    return {"robots": nb, "bytes": BYTES_PER_ROBOT_COLD * nb, "us": evs / steps * 1e6, "achieved": gbs, "unit": "GB/s",
+            "peak": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS,
+            "what": "load -> assemble (PD law, rotation log, Newton-Euler rhs) -> output transform -> store, no QP iterations"}
+
+
 def pmc_traffic(cfg, n):
     """HBM bytes per launch from the newest committed PMC pass of this workload
     (profiles/rNN_cfg<cfg>.json, produced by tools/profile_r.sh +
@@ -188,7 +213,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true", help="skip the informational runs of the other configs")
     ap.add_argument("--probe-batch-load", action="store_true",
-                    help="also time the load -> assemble -> store phase alone (no solver iterations) on 2,097,152 robots")
+                    help="time the load -> assemble -> store phase alone (no solver iterations) on 2,097,152 robots "
+                         "(done by default together with the sweep)")
     args = ap.parse_args()
 
     import torch
@@ -281,18 +307,8 @@ def main():
                                           "what": "joint states + COM state + gait phases -> complete joint torque command "
                                                   "(FK, contact rule, foothold planner, swing trajectories, IK, joint PD, QP, J^T) in one launch"}
             line["other_configs"] = other
-        if world == 1 and args.probe_batch_load:
-            # north_star: "achieved HBM GB/s on the batch load".  Same kernel, solver iterations skipped
-            # (status = max_iter for every robot), batch larger than the 256 MiB Infinity Cache.
-            os.environ["QC_PROBE_BATCH_LOAD"] = "1"
-            probe = q.BalanceController.from_params(P, device=device)
-            del os.environ["QC_PROBE_BATCH_LOAD"]
-            nb = 2097152
-            r = run_config(probe, q, 5, nb, 0, 10, 2, None, device)
-            gbs = BYTES_PER_ROBOT_COLD * nb * 10 / r["event_s"] / 1e9
-            line["batch_load_probe"] = {"robots": nb, "bytes": BYTES_PER_ROBOT_COLD * nb, "us": r["event_s"] / 10 * 1e6,
-                                        "achieved": gbs, "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS,
-                                        "what": "load -> assemble (PD law, rotation log, Newton-Euler rhs) -> output transform -> store, no QP iterations"}
+        if world == 1 and (args.probe_batch_load or not args.no_sweep):
+            line["batch_load_probe"] = batch_load_probe(q, P, device)
         print(json.dumps(line), flush=True)
 
     if dist is not None:
