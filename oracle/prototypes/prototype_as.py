@@ -2,10 +2,10 @@
 'clamped trial' acceleration. Counts EQP solves. Development tool only."""
 import sys, os
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 from oracle import numpy_restatement as R
 from quadruped_control_amd import workloads as W
-from tools.prototype_solver import assemble_batch
+from oracle.prototypes.prototype_solver import assemble_batch
 
 
 class QP:

@@ -7,7 +7,7 @@ algorithm against the oracle before writing HIP.  Not imported by the product.
 """
 import sys, os, time
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 from oracle import numpy_restatement as R
 from quadruped_control_amd import workloads as W
 
