@@ -219,7 +219,7 @@ def test_dense_W_path(q, monkeypatch):
     assert np.max(np.abs(o["grf_body"] - ref2) / scale2) < 1e-6
 
 
-@pytest.mark.parametrize("n", [1000, 40000])  # G = 4 and G = 2 lane groups
+@pytest.mark.parametrize("n", [1000, 40000, 150000])  # G = 4, G = 2 single fill, G = 2 persistent waves
 def test_fused_tick_fk_and_torques(q, n):
     """joint_q in, joint_tau out (SURVEY 8f rows 1+2): device FK -> control -> clamp(J^T f)
     against the oracle's composition, and against the unfused path fed with the oracle's feet."""
@@ -368,7 +368,7 @@ def test_swing_leg_torques(q, n):
         ctl.control_batch_host(bad, want_torques=True)
 
 
-@pytest.mark.parametrize("n", [600, 36000])
+@pytest.mark.parametrize("n", [600, 36000, 140000])  # G = 4; G = 2 single fill; G = 2 persistent waves (dense restock)
 def test_on_device_swing_planning_multi_tick(q, n):
     """SURVEY 8f rank 4, stateful half: foothold planner + sextic swing trajectories kept in a
     per-robot state buffer across ticks; torques and the carried state track the oracle tick by tick."""
@@ -379,7 +379,7 @@ def test_on_device_swing_planning_multi_tick(q, n):
     ctl = q.BalanceController.from_params(P)
     dev_state = q.new_swing_states(n)
     ref_state = O.new_swing_states(n)
-    for tick in range(0, 200, 8):
+    for tick in range(0, 200, 8 if n < 100000 else 40):
         b = _planned_batch(n, tick)
         o = ctl.control_batch_host(dict(b, swing_state=dev_state), want_torques=True)
         ref = O.tick_planned_batch(P, b, ref_state, threads=8)
@@ -390,3 +390,23 @@ def test_on_device_swing_planning_multi_tick(q, n):
         assert np.max(np.abs(dev_state["p_final"][m] - ref_state["p_final"][m])) < 1e-9
         assert np.max(np.abs(o["joint_tau"] - ref["joint_tau"])) < 2e-5, tick
     assert (ref_state["has_traj"] == 1).any()
+
+
+@pytest.mark.parametrize("force", ["QC_FORCE_GENERAL", "QC_FORCE_DENSE"])
+def test_fused_tick_on_general_and_dense_forms(q, monkeypatch, force):
+    """the joint_q / joint_tau / swing extensions are compiled into every kernel form"""
+    from oracle import c_oracle as O
+    from quadruped_control_amd import workloads as W
+
+    P = q.cheetah_params(0.6)
+    b = W.with_swing_references(W.with_joint_angles(W.config3(3000)))
+    monkeypatch.setenv(force, "1")
+    ctl = q.BalanceController.from_params(P)
+    monkeypatch.delenv(force)
+    assert ctl.kernel_name in ("diagW-6x6", "dense-12x12")
+    o = ctl.control_batch_host(b, want_torques=True)
+    ref = O.tick_swing_batch(P, b, threads=8)
+    assert (o["status"] == 0).all()
+    scale = np.maximum(1.0, np.abs(ref["grf_body"]).max(axis=1, keepdims=True))
+    assert np.max(np.abs(o["grf_body"] - ref["grf_body"]) / scale) < 1e-6
+    assert np.max(np.abs(o["joint_tau"] - ref["joint_tau"])) < 2e-5
