@@ -427,3 +427,28 @@ def test_every_contact_pattern(q):
     scale = np.maximum(1.0, np.abs(ref).max(axis=1, keepdims=True))
     assert np.max(np.abs(o["grf_body"] - ref) / scale) < 1e-6
     assert np.all(o["grf_body"][np.repeat(b["stance"] == 0, 3, axis=1)] == 0.0)
+
+
+def test_independent_handles_on_concurrent_streams(q):
+    """distinct handles are independent (include/qc_balance.h): two controllers with different
+    parameters launched back to back on two streams give the same results as run alone."""
+    import torch
+
+    from quadruped_control_amd import workloads as W
+
+    Pa, Pb = q.cheetah_params(0.6), q.cheetah_params(0.9)
+    Pb["fzmax"] = 80.0
+    a, b = q.BalanceController.from_params(Pa), q.BalanceController.from_params(Pb)
+    da, db = q.to_device(W.config3(50000)), q.to_device(W.config2(30000))
+    ra = a.control_batch(da)["grf_body"].clone()
+    rb = b.control_batch(db)["grf_body"].clone()
+    torch.cuda.synchronize()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for _ in range(5):
+        oa = a.control_batch(da, stream=sa)
+        ob = b.control_batch(db, stream=sb)
+        outs.append((oa, ob))
+    torch.cuda.synchronize()
+    for oa, ob in outs:
+        assert torch.equal(oa["grf_body"], ra) and torch.equal(ob["grf_body"], rb)
