@@ -597,8 +597,10 @@ QC_DEV bool eqp_diagw(CParams& P, const Wrench<4 / G>& Wr, const Cube<4 / G>& C,
   for (int r = 0; r < 6; r++) {
 #pragma unroll
     for (int c = 0; c <= r; c++) {
-      const double s = group_sum<G>(M[MI(r, c)]);
-      M[MI(r, c)] = s + (UNIFORM ? (r == c ? P.Vd[r] : 0.0) : P.V[6 * r + c]);
+      double s = group_sum<G>(M[MI(r, c)]);
+      if (!UNIFORM) s += P.V[6 * r + c];
+      else if (r == c) s += P.Vd[r];  // S^-1 is diagonal here: nothing to add off the diagonal
+      M[MI(r, c)] = s;
     }
     rhs[r] = group_sum<G>(rhs[r]) - Wr.b[r];
   }
