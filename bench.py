@@ -185,6 +185,41 @@ def batch_load_probe(q, P, device, nb=2097152, steps=10):
             "what": "load -> assemble (PD law, rotation log, Newton-Euler rhs) -> output transform -> store, no QP iterations"}
 
 
+def host_boundary(ctl, q):
+    """The host-pointer entry points (PCIe staging included; never what `value` reports):
+    config 1 = one robot through the reference-signature control() (qc_control), and configs 2/4 through
+    qc_control_batch_host (pageable numpy arrays in, numpy arrays out)."""
+    from quadruped_control_amd import workloads
+
+    b1 = workloads.config1()
+    names = ctl.leg_names
+    foot_map = {nm: b1["feet"].reshape(-1, 4, 3)[0, i] for i, nm in enumerate(names)}
+    a = (b1["Rwb"][0], b1["Rwb_d"][0], b1["x"][0], b1["xdot"][0], b1["w"][0], b1["x_d"][0], b1["xdot_d"][0], b1["w_d"][0])
+    for _ in range(20):
+        f = ctl.control(*a, foot_map)
+    t0 = time.perf_counter()
+    reps = 200
+    for _ in range(reps):
+        f = ctl.control(*a, foot_map)
+    lat = (time.perf_counter() - t0) / reps
+    _, stance, _, ptrs = ctl._one  # the same record through the bare C entry point
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ctl._lib.qc_control(ctl._h, *ptrs)
+    lat_c = (time.perf_counter() - t0) / reps
+    res = {"config1_control_latency_us": lat * 1e6, "config1_qc_control_latency_us": lat_c * 1e6,
+           "config1_grf_RL": [float(v) for v in f[names[0]]]}
+    for cfg, n in ((2, CONFIG_N[2]), (4, CONFIG_N[4])):
+        hb, _ = make_batch(cfg, n, 0)
+        ctl.control_batch_host(hb)
+        t0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            ctl.control_batch_host(hb)
+        res[f"config{cfg}_host_QPs_per_s"] = n * reps / (time.perf_counter() - t0)
+    return res
+
+
 def pmc_traffic(cfg, n):
     """HBM bytes per launch from the newest committed PMC pass of this workload
     (profiles/rNN_cfg<cfg>.json, produced by tools/profile_r.sh +
@@ -307,6 +342,8 @@ def main():
                                           "what": "joint states + COM state + gait phases -> complete joint torque command "
                                                   "(FK, contact rule, foothold planner, swing trajectories, IK, joint PD, QP, J^T) in one launch"}
             line["other_configs"] = other
+        if world == 1 and not args.no_sweep:
+            line["host_boundary"] = host_boundary(ctl, q)
         if world == 1 and (args.probe_batch_load or not args.no_sweep):
             line["batch_load_probe"] = batch_load_probe(q, P, device)
         print(json.dumps(line), flush=True)

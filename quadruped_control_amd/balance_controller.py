@@ -50,6 +50,7 @@ class BalanceController:
         if len(self.leg_names) != 4:
             raise ValueError("leg_names must hold 4 names (order RL, FL, RR, FR in the reference)")
         self.device = int(device)
+        self._one = None  # control(): single-robot record buffers
         self._h = C.c_void_p()
         self._lib = lib
         rc = lib.qc_create(C.byref(p), self.device, C.byref(self._h))
@@ -112,30 +113,38 @@ class BalanceController:
     # ------------------------------------------------------------ single robot
     def control(self, Rwb, Rwb_d, x, xdot, w, x_d, xdot_d, w_d, foot_map, gait_map=None):
         """Same contract as the reference's control(); returns {leg_name: np.ndarray(3)}."""
-        if gait_map is None:
-            gait_map = make_stance_gait()
-        feet = np.zeros(12)
-        stance = np.zeros(4, dtype=np.uint8)
-        for i, name in enumerate(self.leg_names):
-            feet[3 * i:3 * i + 3] = np.asarray(foot_map[name], dtype=np.float64).reshape(3)  # KeyError == out_of_range
-            stance[i] = 1 if int(gait_map[name][0]) == int(LegState.stance) else 0
-        args = [np.ascontiguousarray(np.asarray(v, dtype=np.float64).reshape(-1))
-                for v in (Rwb, Rwb_d, x, xdot, w, x_d, xdot_d, w_d)]
-        for a, k in zip(args, (9, 9, 3, 3, 3, 3, 3, 3)):
-            if a.size != k:
-                raise ValueError("control(): argument has the wrong size")
-        grf = np.zeros(12)
-        status = np.zeros(1, dtype=np.int32)
-        ptr = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
-        rc = self._lib.qc_control(self._h, *[ptr(a) for a in args], ptr(feet), ptr(stance), ptr(grf), ptr(status))
+        one = self._one
+        if one is None:  # record buffers and their pointers, marshalled once
+            buf = np.zeros(48 + 12)
+            stance = np.zeros(4, dtype=np.uint8)
+            status = np.zeros(1, dtype=np.int32)
+            offs = (0, 9, 18, 21, 24, 27, 30, 33, 36, 48)
+            ptrs = [C.c_void_p(buf.ctypes.data + 8 * o) for o in offs[:9]]
+            ptrs += [C.c_void_p(stance.ctypes.data), C.c_void_p(buf.ctypes.data + 8 * 48), C.c_void_p(status.ctypes.data)]
+            one = self._one = (buf, stance, status, ptrs)
+        buf, stance, status, ptrs = one
+        try:
+            buf[0:9] = np.asarray(Rwb, dtype=np.float64).reshape(9)
+            buf[9:18] = np.asarray(Rwb_d, dtype=np.float64).reshape(9)
+            for o, v in ((18, x), (21, xdot), (24, w), (27, x_d), (30, xdot_d), (33, w_d)):
+                buf[o:o + 3] = np.asarray(v, dtype=np.float64).reshape(3)
+        except ValueError:
+            raise ValueError("control(): argument has the wrong size") from None
+        names = self.leg_names
+        for i in range(4):
+            name = names[i]
+            buf[36 + 3 * i:39 + 3 * i] = np.asarray(foot_map[name], dtype=np.float64).reshape(3)  # KeyError == out_of_range
+            stance[i] = 1 if gait_map is None or int(gait_map[name][0]) == 1 else 0  # LegState.stance == 1
+        rc = self._lib.qc_control(self._h, *ptrs)
         if rc != _lib.QC_OK:
             raise RuntimeError(f"qc_control failed ({rc}): {_lib.last_error()}")
         force_map = {}
         if status[0] != 0:
             return force_map  # reference: ROS_ERROR + empty ForceMap
-        for i, name in enumerate(self.leg_names):
+        grf = buf[48:60]
+        for i in range(4):
             if stance[i]:
-                force_map[name] = grf[3 * i:3 * i + 3].copy()
+                force_map[names[i]] = grf[3 * i:3 * i + 3].copy()
         return force_map
 
     # ------------------------------------------------------------------ batches

@@ -511,6 +511,7 @@ struct qc_handle {
   // staging buffers for the host-pointer entry points
   void* stage;
   size_t stage_bytes;
+  void* pin;  // pinned host buffer the kernel reads/writes in place for small batches
   hipStream_t stream;
 };
 
@@ -682,6 +683,7 @@ int qc_create(const qc_params* p, int device, qc_handle** out) {
   h->diag_w = diag;
   h->stage = nullptr;
   h->stage_bytes = 0;
+  h->pin = nullptr;
   h->stream = nullptr;
   h->d_params = nullptr;
   qc::DevParams& d = h->dp;
@@ -762,6 +764,7 @@ void qc_destroy(qc_handle* h) {
   (void)hipSetDevice(h->device);
   if (h->d_params) (void)hipFree(h->d_params);
   if (h->stage) (void)hipFree(h->stage);
+  if (h->pin) (void)hipHostFree(h->pin);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -824,7 +827,11 @@ int qc_control_batch(qc_handle* h, size_t n, const qc_batch_in* in, const uint32
   return QC_OK;
 }
 
-// host-pointer variant: one staging allocation, H2D, kernel, D2H, sync
+// host-pointer variant.  Large batches: one device staging allocation, H2D copies, kernel, D2H copies, sync.
+// Small batches (n <= kPinnedMaxN, the reference's own use: one robot per controller tick): the records are packed
+// into a pinned, device-visible host buffer that the kernel reads and writes in place over PCIe - one launch and one
+// stream synchronise instead of a dozen staged copies.
+static constexpr size_t kPinnedMaxN = 64;
 int qc_control_batch_host(qc_handle* h, size_t n, const qc_batch_in* in, const uint32_t* warm, const qc_batch_out* out) {
   if (!h || !in || !out) return fail(QC_ERR_INVALID, "qc_control_batch_host: null argument");
   if (n == 0) return QC_OK;
@@ -834,80 +841,76 @@ int qc_control_batch_host(qc_handle* h, size_t n, const qc_batch_in* in, const u
   if (!out->grf_body || !out->status) return fail(QC_ERR_INVALID, "qc_control_batch_host: grf_body and status are required");
   QC_HIP(hipSetDevice(h->device));
   if (!h->stream) QC_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-  // layout (all 8-byte aligned): 48 doubles in, 12 doubles out, 4 x 4-byte words
+  const bool pinned = n <= kPinnedMaxN;
+  // layout (all 16-byte aligned slices): 48 doubles in, 12 doubles out, 4 x 4-byte words, optional arrays
   const size_t per = 48 * 8 + 12 * 8 + 4 * 4 + 8 + 12 * 8 + 12 * 8 + 5 * 8 + 3 * 12 * 8 + sizeof(qc_swing_state);
-  const size_t need = n * per + 256;
-  if (need > h->stage_bytes) {
-    if (h->stage) QC_HIP(hipFree(h->stage));
-    h->stage = nullptr; h->stage_bytes = 0;
-    QC_HIP(hipMalloc(&h->stage, need));
-    h->stage_bytes = need;
+  const size_t need = n * per + 512;
+  char* base;
+  if (pinned) {
+    if (!h->pin) QC_HIP(hipHostMalloc(&h->pin, kPinnedMaxN * per + 512, hipHostMallocDefault));
+    base = (char*)h->pin;
+  } else {
+    if (need > h->stage_bytes) {
+      if (h->stage) QC_HIP(hipFree(h->stage));
+      h->stage = nullptr; h->stage_bytes = 0;
+      QC_HIP(hipMalloc(&h->stage, need));
+      h->stage_bytes = need;
+    }
+    base = (char*)h->stage;
   }
-  char* base = (char*)h->stage;
   size_t off = 0;
   auto carve = [&](size_t bytes) { char* p = base + off; off += (bytes + 15) & ~(size_t)15; return p; };
-  const size_t szs[9] = {9, 9, 3, 3, 3, 3, 3, 3, 12};
-  const double* src[9] = {in->Rwb, in->Rwb_d, in->x, in->xdot, in->w, in->x_d, in->xdot_d, in->w_d, in->feet};
-  double* dptr[9];
-  for (int k = 0; k < 9; k++) {
-    dptr[k] = nullptr;
-    if (!src[k]) continue;  // feet may be absent when joint_q is given
-    dptr[k] = (double*)carve(n * szs[k] * 8);
-    QC_HIP(hipMemcpyAsync(dptr[k], src[k], n * szs[k] * 8, hipMemcpyHostToDevice, h->stream));
-  }
-  double* d_q = nullptr;
-  if (in->joint_q) {
-    d_q = (double*)carve(n * 12 * 8);
-    QC_HIP(hipMemcpyAsync(d_q, in->joint_q, n * 12 * 8, hipMemcpyHostToDevice, h->stream));
-  }
-  double* d_tau = out->joint_tau ? (double*)carve(n * 12 * 8) : nullptr;
-  double *d_gp = nullptr, *d_gd = nullptr;
-  if (in->gait_phase) {
-    d_gp = (double*)carve(n * 4 * 8);
-    QC_HIP(hipMemcpyAsync(d_gp, in->gait_phase, n * 4 * 8, hipMemcpyHostToDevice, h->stream));
-  }
-  if (in->gait_duty) {
-    d_gd = (double*)carve(n * 8);
-    QC_HIP(hipMemcpyAsync(d_gd, in->gait_duty, n * 8, hipMemcpyHostToDevice, h->stream));
-  }
-  const double* sw_src[3] = {in->swing_pos, in->swing_vel, in->joint_qdot};
-  double* d_sw[3] = {nullptr, nullptr, nullptr};
-  for (int k = 0; k < 3; k++)
-    if (sw_src[k]) {
-      d_sw[k] = (double*)carve(n * 12 * 8);
-      QC_HIP(hipMemcpyAsync(d_sw[k], sw_src[k], n * 12 * 8, hipMemcpyHostToDevice, h->stream));
-    }
-  uint8_t* d_st = nullptr;
-  if (in->stance) {
-    d_st = (uint8_t*)carve(n * 4);
-    QC_HIP(hipMemcpyAsync(d_st, in->stance, n * 4, hipMemcpyHostToDevice, h->stream));
-  }
-  uint32_t* d_warm = nullptr;
-  if (warm) {
-    d_warm = (uint32_t*)carve(n * 4);
-    QC_HIP(hipMemcpyAsync(d_warm, warm, n * 4, hipMemcpyHostToDevice, h->stream));
-  }
-  qc_swing_state* d_ss = nullptr;
-  if (in->swing_state) {
-    d_ss = (qc_swing_state*)carve(n * sizeof(qc_swing_state));
-    QC_HIP(hipMemcpyAsync(d_ss, in->swing_state, n * sizeof(qc_swing_state), hipMemcpyHostToDevice, h->stream));
-  }
-  double* d_grf = (double*)carve(n * 12 * 8);
-  int32_t* d_status = (int32_t*)carve(n * 4);
-  uint32_t* d_act = out->active_set ? (uint32_t*)carve(n * 4) : nullptr;
-  int32_t* d_it = out->iterations ? (int32_t*)carve(n * 4) : nullptr;
-  if (off > h->stage_bytes) return fail(QC_ERR_INVALID, "qc_control_batch_host: staging overflow");
-  qc_batch_in din{dptr[0], dptr[1], dptr[2], dptr[3], dptr[4], dptr[5], dptr[6], dptr[7], dptr[8], d_st, d_q, d_gp, d_gd, d_sw[0], d_sw[1], d_sw[2], d_ss};
-  qc_batch_out dout{d_grf, d_status, d_act, d_it, d_tau};
+  hipError_t cerr = hipSuccess;
+  auto put = [&](const void* src, size_t bytes) -> void* {  // input slice: carve + host -> buffer
+    if (!src) return nullptr;
+    char* d = carve(bytes);
+    if (pinned) std::memcpy(d, src, bytes);
+    else if (cerr == hipSuccess) cerr = hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, h->stream);
+    return d;
+  };
+  auto get = [&](void* dst, const void* d, size_t bytes) {  // output slice: buffer -> host
+    if (!dst || !d) return;
+    if (pinned) std::memcpy(dst, d, bytes);
+    else if (cerr == hipSuccess) cerr = hipMemcpyAsync(dst, d, bytes, hipMemcpyDeviceToHost, h->stream);
+  };
+  qc_batch_in din{};
+  din.Rwb = (const double*)put(in->Rwb, n * 9 * 8);
+  din.Rwb_d = (const double*)put(in->Rwb_d, n * 9 * 8);
+  din.x = (const double*)put(in->x, n * 3 * 8);
+  din.xdot = (const double*)put(in->xdot, n * 3 * 8);
+  din.w = (const double*)put(in->w, n * 3 * 8);
+  din.x_d = (const double*)put(in->x_d, n * 3 * 8);
+  din.xdot_d = (const double*)put(in->xdot_d, n * 3 * 8);
+  din.w_d = (const double*)put(in->w_d, n * 3 * 8);
+  din.feet = (const double*)put(in->feet, n * 12 * 8);  // may be absent when joint_q is given
+  din.stance = (const uint8_t*)put(in->stance, n * 4);
+  din.joint_q = (const double*)put(in->joint_q, n * 12 * 8);
+  din.gait_phase = (const double*)put(in->gait_phase, n * 4 * 8);
+  din.gait_duty = (const double*)put(in->gait_duty, n * 8);
+  din.swing_pos = (const double*)put(in->swing_pos, n * 12 * 8);
+  din.swing_vel = (const double*)put(in->swing_vel, n * 12 * 8);
+  din.joint_qdot = (const double*)put(in->joint_qdot, n * 12 * 8);
+  din.swing_state = (qc_swing_state*)put(in->swing_state, n * sizeof(qc_swing_state));  // in/out
+  const uint32_t* d_warm = (const uint32_t*)put(warm, n * 4);
+  qc_batch_out dout{};
+  dout.grf_body = (double*)carve(n * 12 * 8);
+  dout.status = (int32_t*)carve(n * 4);
+  dout.active_set = out->active_set ? (uint32_t*)carve(n * 4) : nullptr;
+  dout.iterations = out->iterations ? (int32_t*)carve(n * 4) : nullptr;
+  dout.joint_tau = out->joint_tau ? (double*)carve(n * 12 * 8) : nullptr;
+  QC_HIP(cerr);
+  if (off > (pinned ? kPinnedMaxN * per + 512 : h->stage_bytes)) return fail(QC_ERR_INVALID, "qc_control_batch_host: staging overflow");
   int rc = qc_control_batch(h, n, &din, d_warm, &dout, h->stream);
   if (rc != QC_OK) return rc;
-  QC_HIP(hipMemcpyAsync(out->grf_body, d_grf, n * 12 * 8, hipMemcpyDeviceToHost, h->stream));
-  QC_HIP(hipMemcpyAsync(out->status, d_status, n * 4, hipMemcpyDeviceToHost, h->stream));
-  if (d_act) QC_HIP(hipMemcpyAsync(out->active_set, d_act, n * 4, hipMemcpyDeviceToHost, h->stream));
-  if (d_it) QC_HIP(hipMemcpyAsync(out->iterations, d_it, n * 4, hipMemcpyDeviceToHost, h->stream));
-  if (d_tau) QC_HIP(hipMemcpyAsync(out->joint_tau, d_tau, n * 12 * 8, hipMemcpyDeviceToHost, h->stream));
-  if (d_ss) QC_HIP(hipMemcpyAsync(in->swing_state, d_ss, n * sizeof(qc_swing_state), hipMemcpyDeviceToHost, h->stream));
-  QC_HIP(hipStreamSynchronize(h->stream));
+  if (pinned) QC_HIP(hipStreamSynchronize(h->stream));  // kernel-end release makes the in-place results visible
+  get(out->grf_body, dout.grf_body, n * 12 * 8);
+  get(out->status, dout.status, n * 4);
+  get(out->active_set, dout.active_set, n * 4);
+  get(out->iterations, dout.iterations, n * 4);
+  get(out->joint_tau, dout.joint_tau, n * 12 * 8);
+  get(in->swing_state, din.swing_state, n * sizeof(qc_swing_state));
+  QC_HIP(cerr);
+  if (!pinned) QC_HIP(hipStreamSynchronize(h->stream));
   return QC_OK;
 }
 
