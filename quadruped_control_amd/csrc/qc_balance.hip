@@ -58,15 +58,18 @@ struct Lane {
   int status, iters;
   bool have_f;
 
-  QC_DEV double lo(CParams& P, int i) const { return ((stance >> (foot0 + i)) & 1u) ? P.fzmin : 0.0; }
-  QC_DEV double hi(CParams& P, int i) const { return ((stance >> (foot0 + i)) & 1u) ? P.fzmax : 0.0; }
+  template <class PT>
+  QC_DEV double lo(const PT& P, int i) const { return ((stance >> (foot0 + i)) & 1u) ? P.fzmin : 0.0; }
+  template <class PT>
+  QC_DEV double hi(const PT& P, int i) const { return ((stance >> (foot0 + i)) & 1u) ? P.fzmax : 0.0; }
 
   // multiplier test on the current face: true if all active faces have
   // lambda >= -tol; otherwise wcode = 3*foot+axis of the most negative one.
-  QC_DEV bool multipliers_ok(CParams& P, const double (&g)[3 * FPL], int& wcode) const {
+  template <class PT>
+  QC_DEV bool multipliers_ok(const PT& P, const double (&g)[3 * FPL], int& wcode) const {
     double gs = 1.0;
 #pragma unroll
-    for (int k = 0; k < 3 * FPL; k++) gs = fmax(gs, fabs(g[k]));
+    for (int k = 0; k < 3 * FPL; k++) gs = max_abs_nn(gs, g[k]);
     gs = group_max<G>(gs);
     double cand[3 * FPL];
 #pragma unroll
@@ -82,7 +85,7 @@ struct Lane {
 #pragma unroll
     for (int w = 3 * FPL; w > 1; w = (w + 1) / 2)
 #pragma unroll
-      for (int k = 0; k < w / 2; k++) cand[k] = fmin(cand[k], cand[k + (w + 1) / 2]);
+      for (int k = 0; k < w / 2; k++) cand[k] = min_nn(cand[k], cand[k + (w + 1) / 2]);
     const double worst = group_min<G>(cand[0]);
     const bool ok = !(worst < -P.tol_d * gs);
     wcode = ok ? -1 : tag_code(worst);
@@ -90,7 +93,8 @@ struct Lane {
   }
 
   // one working-set recalculation; returns true when the robot is finished
-  QC_DEV bool iterate(CParams& P, Eqp& eqp) {
+  template <class PT>
+  QC_DEV bool iterate(const PT& P, Eqp& eqp) {
     double fh[3 * FPL], g[3 * FPL];
     if (P.max_iter == 0) return true;  // measurement probe (QC_PROBE_BATCH_LOAD): load -> assemble -> store only
     iters++;
@@ -133,12 +137,12 @@ struct Lane {
 #pragma unroll
     for (int w = 6 * FPL; w > 1; w = (w + 1) / 2)
 #pragma unroll
-      for (int k = 0; k < w / 2; k++) cand[k] = fmin(cand[k], cand[k + (w + 1) / 2]);
+      for (int k = 0; k < w / 2; k++) cand[k] = min_nn(cand[k], cand[k + (w + 1) / 2]);
     const double amin = group_min<G>(cand[0]);
     const bool blocked = !fresh && (amin < 1.0e299);
     const int bcode = blocked ? tag_code(amin) : -1;
     // f <- f^ + (1 - alpha)(f - f^): exactly f^ for a full step
-    const double beta = blocked ? 1.0 - fmax(amin, 0.0) : 0.0;
+    const double beta = blocked ? 1.0 - max_nn(amin, 0.0) : 0.0;
 #pragma unroll
     for (int k = 0; k < 3 * FPL; k++) f[k] = fresh ? fc[k] : __builtin_fma(beta, f[k] - fh[k], fh[k]);
     // multiplier test, meaningful when f landed on f^
@@ -418,7 +422,7 @@ QC_DEV void flush_out(const DevParams* __restrict__ Pg, const BatchIn& in, const
   }
 }
 
-template <class Eqp, bool KIN, int MIN_WAVES_PER_SIMD>
+template <class Eqp, bool KIN, int MIN_WAVES_PER_SIMD, bool RESIDENT = false>
 __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const DevParams* __restrict__ Pg, const long n, const BatchIn in,
                                                                          const uint32_t* __restrict__ warm, const BatchOut out, const long chunk,
                                                                          const int refill_t) {
@@ -437,6 +441,33 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
   L.foot0 = member * (4 / G);
   Eqp eqp(qc_lds + STOCK_DOUBLES + lane);
   bool busy = false;  // group holds an unfinished robot
+  QC_CLK_BEGIN();
+  UConst uc;  // RESIDENT: the recalculation's constants live in VGPRs for the whole kernel
+  if constexpr (RESIDENT) uc = load_uconst(*QC_PARAMS_HERE(Pg));
+  if constexpr (RESIDENT) {
+    // Small batch: the launch gives every wave at most one fill (chunk <= 64 / G) and the SIMD to itself, so the
+    // persistent-wave machinery (refill, stock cursors, per-recalculation result pushes) is dead weight on the
+    // serial chain that bounds the batch.  One fill, a divergent solve loop, one push, one flush.
+    if (cursor >= end) return;
+    stock_n = restock<G, KIN>(Pg, in, warm, cursor, end, lane, member, sin);
+    const int grp = lane / G;
+    busy = grp < stock_n;
+    if (busy) {
+      L.load_from_stock(sin, grp, member);
+      eqp.setup(*QC_PARAMS_HERE(Pg), L.Wr);
+    }
+    QC_CLK(0, 2);
+    while (busy) {
+      pin_uconst(uc);
+      busy = !L.iterate(uc, eqp);
+    }
+    QC_CLK(7, 8);
+    if (grp < stock_n) L.push_result(sout, grp);
+    __syncthreads();
+    flush_out<Eqp::G, KIN>(Pg, in, out, sout, stock_n, lane);
+    QC_CLK_END(8);
+    return;
+  }
   // The first restock runs before any solver state is live, so (unlike its copy
   // inside the loop) it needs no spills: batches that fit one fill per wave
   // never execute the in-loop copy.
@@ -444,6 +475,7 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
     stock_n = restock<G, KIN>(Pg, in, warm, cursor, end, lane, member, sin);
     cursor += stock_n;
   }
+  QC_CLK(0, 1);
   for (;;) {
     const unsigned long long busy_mask = __builtin_amdgcn_ballot_w64(busy);
     const int n_free = (64 - __builtin_popcountll(busy_mask)) / G;  // free groups
@@ -470,8 +502,15 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
     bool fin = false;
     if (busy) {
       asm volatile("; QC_ITER_BEGIN");
-      CParams& P = *QC_PARAMS_HERE(Pg);
-      fin = L.iterate(P, eqp);
+      QC_CLK(1, 2);
+      if constexpr (RESIDENT) {
+        pin_uconst(uc);
+        fin = L.iterate(uc, eqp);
+      } else {
+        CParams& P = *QC_PARAMS_HERE(Pg);
+        fin = L.iterate(P, eqp);
+      }
+      QC_CLK(7, 1);
       asm volatile("; QC_ITER_END");
     }
     const unsigned long long fin_mask = __builtin_amdgcn_ballot_w64(fin);
@@ -492,7 +531,9 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
     }
   }
   __syncthreads();
+  QC_CLK(1, 8);
   flush_out<Eqp::G, KIN>(Pg, in, out, sout, out_n, lane);
+  QC_CLK_END(8);
 }
 
 }  // namespace qc
@@ -508,6 +549,7 @@ struct qc_handle {
   int refill_t;         // parked lanes that trigger a refill
   long chunk_override;  // development knob (QC_CHUNK)
   int group_override;   // development knob (QC_GROUP): lanes per robot
+  bool no_resident;     // development knob (QC_NO_RESIDENT): never take the one-wave-per-SIMD variant
   // staging buffers for the host-pointer entry points
   void* stage;
   size_t stage_bytes;
@@ -750,6 +792,7 @@ int qc_create(const qc_params* p, int device, qc_handle** out) {
   if (const char* e = std::getenv("QC_WAVE_SLOTS")) h->wave_slots = std::atoi(e);
   h->group_override = 0;
   if (const char* e = std::getenv("QC_GROUP")) { const int g = std::atoi(e); if (g == 1 || g == 2 || g == 4) h->group_override = g; }
+  h->no_resident = std::getenv("QC_NO_RESIDENT") != nullptr;
   if (hipSetDevice(device) != hipSuccess || hipMalloc((void**)&h->d_params, sizeof(qc::DevParams)) != hipSuccess ||
       hipMemcpy(h->d_params, &h->dp, sizeof(qc::DevParams), hipMemcpyHostToDevice) != hipSuccess) {
     delete h;
@@ -811,14 +854,15 @@ int qc_control_batch(qc_handle* h, size_t n, const qc_batch_in* in, const uint32
   const unsigned blocks = (unsigned)(((long)n + chunk - 1) / chunk);
   const int refill_t = h->refill_t > 0 ? (h->refill_t + G - 1) / G : 1;
   const hipStream_t st = (hipStream_t)stream;
-#define QC_LAUNCH(EQP, MINW, LDS)                                                                                                    \
+#define QC_LAUNCH(EQP, MINW, LDS, ...)                                                                                               \
   do {                                                                                                                              \
-    if (kin) qc::balance_kernel<EQP, true, MINW><<<dim3(blocks), dim3(64), LDS, st>>>(h->d_params, (long)n, bi, warm, bo, chunk, refill_t);  \
-    else qc::balance_kernel<EQP, false, MINW><<<dim3(blocks), dim3(64), LDS, st>>>(h->d_params, (long)n, bi, warm, bo, chunk, refill_t);     \
+    if (kin) qc::balance_kernel<EQP, true, MINW, ##__VA_ARGS__><<<dim3(blocks), dim3(64), LDS, st>>>(h->d_params, (long)n, bi, warm, bo, chunk, refill_t);  \
+    else qc::balance_kernel<EQP, false, MINW, ##__VA_ARGS__><<<dim3(blocks), dim3(64), LDS, st>>>(h->d_params, (long)n, bi, warm, bo, chunk, refill_t);     \
   } while (0)
   constexpr size_t kStock = qc::STOCK_DOUBLES * sizeof(double);
   if (!h->diag_w) QC_LAUNCH(qc::EqpDense, 1, kStock + 78 * 64 * sizeof(double));
   else if (!h->uniform) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<false, 1>), 2, kStock);
+  else if (G == 4 && chunk <= rpw && (long)blocks * 2 <= slots && !h->no_resident) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<true, 4>), 1, kStock, true);  // one wave per SIMD
   else if (G == 4) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<true, 4>), 2, kStock);
   else if (G == 2) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<true, 2>), 2, kStock);
   else QC_LAUNCH(QC_COMMA(qc::EqpDiagW<true, 1>), 2, kStock);

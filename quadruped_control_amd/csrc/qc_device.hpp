@@ -21,6 +21,13 @@
 #include <stdint.h>
 
 #define QC_DEV __device__ __forceinline__
+// Phase-clock hooks: empty in the product; tools/phase_clock.hip defines them to attribute cycles to phases.
+#ifndef QC_CLK
+#define QC_CLK(from, to)
+#define QC_CLK_BEGIN()
+#define QC_CLK_END(last)
+#define QC_CLK_PIN(arr)  // harness: pins the values of `arr` at this point so the scheduler cannot move a phase across its marker
+#endif
 
 namespace qc {
 
@@ -68,6 +75,31 @@ typedef const __attribute__((address_space(4))) DevParams CParams;
     (CParams*)(unsigned long long)p_;      \
   })
 
+// The handful of constants one working-set recalculation of the UNIFORM form reads, as a register-resident
+// copy (VGPRs, pinned): used by the one-wave-per-SIMD launch of small batches, where a scalar load + wait at the
+// top of every recalculation is exposed latency (no second wave to hide it) and the VGPR budget is 512.
+struct UConst {
+  double mu, fzmin, fzmax, inv_w_u, w_u, tol_d;
+  double inv_bz_u[3], Vd[6];
+  int max_iter;
+};
+QC_DEV UConst load_uconst(CParams& P) {
+  UConst u;
+  u.mu = P.mu; u.fzmin = P.fzmin; u.fzmax = P.fzmax; u.inv_w_u = P.inv_w_u; u.w_u = P.w_u; u.tol_d = P.tol_d;
+#pragma unroll
+  for (int k = 0; k < 3; k++) u.inv_bz_u[k] = P.inv_bz_u[k];
+#pragma unroll
+  for (int k = 0; k < 6; k++) u.Vd[k] = P.Vd[k];
+  u.max_iter = P.max_iter;
+  return u;
+}
+// keeps the copy where it is (in VGPRs) instead of letting the compiler re-load it from the constant buffer
+QC_DEV void pin_uconst(UConst& u) {
+  asm volatile("" : "+v"(u.mu), "+v"(u.fzmin), "+v"(u.fzmax), "+v"(u.inv_w_u), "+v"(u.w_u), "+v"(u.tol_d));
+  asm volatile("" : "+v"(u.inv_bz_u[0]), "+v"(u.inv_bz_u[1]), "+v"(u.inv_bz_u[2]));
+  asm volatile("" : "+v"(u.Vd[0]), "+v"(u.Vd[1]), "+v"(u.Vd[2]), "+v"(u.Vd[3]), "+v"(u.Vd[4]), "+v"(u.Vd[5]), "+v"(u.max_iter));
+}
+
 // mirrors qc_swing_state (include/qc_balance.h)
 struct SwingState {
   int32_t leg_state[4];
@@ -109,6 +141,24 @@ QC_DEV double dpp_xor2(double v) {
   const unsigned lo = (unsigned)dpp_xor2_i((int)(unsigned)b), hi = (unsigned)dpp_xor2_i((int)(unsigned)(b >> 32));
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
+// min/max of values known to be non-NaN (tagged candidates, magnitudes): the bare instruction.  fmin()/fmax()
+// make the compiler quiet every operand first (v_max_f64 x, x, x) because it cannot prove there is no sNaN,
+// which doubles the length of the arg-min trees on the serial chain.
+QC_DEV double min_nn(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+QC_DEV double max_nn(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+QC_DEV double max_abs_nn(double a, double b) {  // max(|a|, |b|)
+  double r;
+  asm("v_max_f64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 // All-reduce over the G lanes of a group.  x op y is commutative, so every
 // lane of the group ends up with the bit-identical result: decisions taken
 // from reduced values are uniform inside the group.
@@ -120,14 +170,14 @@ QC_DEV double group_sum(double v) {
 }
 template <int G>
 QC_DEV double group_min(double v) {
-  if (G >= 2) v = fmin(v, dpp_xor1(v));
-  if (G >= 4) v = fmin(v, dpp_xor2(v));
+  if (G >= 2) v = min_nn(v, dpp_xor1(v));
+  if (G >= 4) v = min_nn(v, dpp_xor2(v));
   return v;
 }
 template <int G>
 QC_DEV double group_max(double v) {
-  if (G >= 2) v = fmax(v, dpp_xor1(v));
-  if (G >= 4) v = fmax(v, dpp_xor2(v));
+  if (G >= 2) v = max_nn(v, dpp_xor1(v));
+  if (G >= 4) v = max_nn(v, dpp_xor2(v));
   return v;
 }
 template <int G>
@@ -508,13 +558,13 @@ struct FootCoef {
 // UNIFORM = (S diagonal, W = w*I): a handful of scalar constants instead of
 // ~60, so they all stay in SGPRs.  The per-foot constant tables of the general
 // form are indexed with the compile-time foot number, hence G = 1 only there.
-template <bool UNIFORM>
-QC_DEV FootCoef foot_coef(CParams& P, int sx, int sy, int sz, bool st, int foot) {
+template <bool UNIFORM, class PT>
+QC_DEV FootCoef foot_coef(const PT& P, int sx, int sy, int sz, bool st, int foot) {
   FootCoef k;
   k.mx = P.mu * (double)sx;
   k.my = P.mu * (double)sy;
   k.fzfix = st ? (sz > 0 ? P.fzmax : (sz < 0 ? P.fzmin : 0.0)) : 0.0;
-  if (UNIFORM) {
+  if constexpr (UNIFORM) {
     k.ix = (st && sx == 0) ? P.inv_w_u : 0.0;
     k.iy = (st && sy == 0) ? P.inv_w_u : 0.0;
     const double b1 = sy != 0 ? P.inv_bz_u[2] : P.inv_bz_u[1];
@@ -531,8 +581,8 @@ QC_DEV FootCoef foot_coef(CParams& P, int sx, int sy, int sz, bool st, int foot)
 }
 
 // `stance` = 4-bit mask of the robot, `foot0` = first foot of this lane.
-template <bool UNIFORM, int G>
-QC_DEV bool eqp_diagw(CParams& P, const Wrench<4 / G>& Wr, const Cube<4 / G>& C, uint32_t stance, int foot0, double (&f)[12 / G],
+template <bool UNIFORM, int G, class PT>
+QC_DEV bool eqp_diagw(const PT& P, const Wrench<4 / G>& Wr, const Cube<4 / G>& C, uint32_t stance, int foot0, double (&f)[12 / G],
                       double (&g)[12 / G]) {
   constexpr int FPL = 4 / G;
   static_assert(UNIFORM || G == 1, "per-foot weight tables need compile-time foot numbers");
@@ -592,18 +642,22 @@ QC_DEV bool eqp_diagw(CParams& P, const Wrench<4 / G>& Wr, const Cube<4 / G>& C,
       for (int r = c; r < 6; r++) M[MI(r, c)] = __builtin_fma(q[r], tq, M[MI(r, c)]);
     }
   }
+  QC_CLK_PIN(M); QC_CLK_PIN(rhs);
+  QC_CLK(2, 3);
   // combine the group's partial sums, then add S^-1 and -b
 #pragma unroll
   for (int r = 0; r < 6; r++) {
 #pragma unroll
     for (int c = 0; c <= r; c++) {
       double s = group_sum<G>(M[MI(r, c)]);
-      if (!UNIFORM) s += P.V[6 * r + c];
+      if constexpr (!UNIFORM) s += P.V[6 * r + c];
       else if (r == c) s += P.Vd[r];  // S^-1 is diagonal here: nothing to add off the diagonal
       M[MI(r, c)] = s;
     }
     rhs[r] = group_sum<G>(rhs[r]) - Wr.b[r];
   }
+  QC_CLK_PIN(M); QC_CLK_PIN(rhs);
+  QC_CLK(3, 4);
   // Cholesky M = L L^T (in place; diagonal holds 1/L_kk)
   bool ok = true;
 #pragma unroll
@@ -622,6 +676,8 @@ QC_DEV bool eqp_diagw(CParams& P, const Wrench<4 / G>& Wr, const Cube<4 / G>& C,
       M[MI(r, k)] = t * rinv;
     }
   }
+  QC_CLK_PIN(M);
+  QC_CLK(4, 5);
   // solve L L^T v = rhs
   double v[6];
 #pragma unroll
@@ -639,6 +695,8 @@ QC_DEV bool eqp_diagw(CParams& P, const Wrench<4 / G>& Wr, const Cube<4 / G>& C,
     v[k] = t * M[MI(k, k)];
   }
 #undef MI
+  QC_CLK_PIN(v);
+  QC_CLK(5, 6);
   // pass 2: forces and gradient of this lane's feet
 #pragma unroll
   for (int i = 0; i < FPL; i++) {
@@ -653,10 +711,17 @@ QC_DEV bool eqp_diagw(CParams& P, const Wrench<4 / G>& Wr, const Cube<4 / G>& C,
     const double fx = __builtin_fma(k.mx, fz, -k.ix * ax);
     const double fy = __builtin_fma(k.my, fz, -k.iy * ay);
     f[3 * i] = fx; f[3 * i + 1] = fy; f[3 * i + 2] = fz;
-    g[3 * i] = 2.0 * __builtin_fma(UNIFORM ? P.w_u : P.w[3 * (G == 1 ? i : 0)], fx, ax);
-    g[3 * i + 1] = 2.0 * __builtin_fma(UNIFORM ? P.w_u : P.w[3 * (G == 1 ? i : 0) + 1], fy, ay);
-    g[3 * i + 2] = 2.0 * __builtin_fma(UNIFORM ? P.w_u : P.w[3 * (G == 1 ? i : 0) + 2], fz, az);
+    double wx, wy, wz;
+    if constexpr (UNIFORM) wx = wy = wz = P.w_u;
+    else { wx = P.w[3 * (G == 1 ? i : 0)]; wy = P.w[3 * (G == 1 ? i : 0) + 1]; wz = P.w[3 * (G == 1 ? i : 0) + 2]; }
+    g[3 * i] = 2.0 * __builtin_fma(wx, fx, ax);
+    g[3 * i + 1] = 2.0 * __builtin_fma(wy, fy, ay);
+    g[3 * i + 2] = 2.0 * __builtin_fma(wz, fz, az);
   }
+  QC_CLK_PIN(f); QC_CLK_PIN(g);
+  QC_CLK(6, 7);
+  QC_CLK(7, 9);  // empty phase: the cost of one marker
+  QC_CLK(9, 7);
   return ok;
 }
 
@@ -665,7 +730,8 @@ struct EqpDiagW {
   static constexpr int G = GROUP;
   QC_DEV explicit EqpDiagW(double*) {}
   QC_DEV void setup(CParams&, const Wrench<4 / GROUP>&) {}
-  QC_DEV bool solve(CParams& P, const Wrench<4 / GROUP>& Wr, const Cube<4 / GROUP>& C, uint32_t stance, int foot0, double (&f)[12 / GROUP],
+  template <class PT>
+  QC_DEV bool solve(const PT& P, const Wrench<4 / GROUP>& Wr, const Cube<4 / GROUP>& C, uint32_t stance, int foot0, double (&f)[12 / GROUP],
                     double (&g)[12 / GROUP]) {
     return eqp_diagw<UNIFORM, GROUP>(P, Wr, C, stance, foot0, f, g);
   }

@@ -1,0 +1,37 @@
+"""Development tool: where the cycles of one wave go (needs tools/_build/libqc_balance_clk.so, see phase_clock.hip).
+usage: python tools/phase_clock.py [n=4096] [config=2]"""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+import numpy as np, torch
+from quadruped_control_amd import _lib
+_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "libqc_balance_clk.so")
+import quadruped_control_amd as q
+from quadruped_control_amd import workloads as W
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+cfg = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+ctl = q.BalanceController.from_params(q.cheetah_params(0.6))
+lib = ctl._lib
+b = q.to_device({2: W.config2, 3: W.config3}[cfg](n))
+launch, out = ctl.plan_batch(b)
+NAMES = ["first restock", "loop/refill/push", "coef + local M", "group reduce", "cholesky", "tri solves", "forces+grad",
+         "ratio/mult/update", "final flush", "(one marker)"]
+buf = (C.c_ulonglong * 16)()
+for _ in range(3):
+    launch()
+torch.cuda.synchronize()
+lib.qc_clk_read(buf, 1)
+reps = 20
+for _ in range(reps):
+    launch()
+torch.cuda.synchronize()
+lib.qc_clk_read(buf, 1)
+v = np.array(list(buf), dtype=np.uint64).astype(np.int64) / reps
+its = v[10]
+print("kernel %s, n=%d: block 0 made %.1f iterate calls per launch; %.0f cycles = %.2f us (s_memtime %.0f MHz)" %
+      (ctl.kernel_name, n, its, v[12], v[11] / 100.0, v[12] / (v[11] / 100.0)))
+for k, nm in enumerate(NAMES):
+    per = v[k] / its if 2 <= k <= 7 or k == 9 else float("nan")
+    print("  %-20s %9.0f cycles total  %8.0f per iterate" % (nm, v[k], per))
+mk = v[9] / its
+print("  sum of iterate phases per call: %.0f cycles, of which markers ~%.0f (8 x %.0f)" % ((v[2:8].sum() + v[9]) / its, 8 * mk, mk))
