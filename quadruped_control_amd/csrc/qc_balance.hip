@@ -422,7 +422,9 @@ QC_DEV void flush_out(const DevParams* __restrict__ Pg, const BatchIn& in, const
   }
 }
 
-template <class Eqp, bool KIN, int MIN_WAVES_PER_SIMD, bool RESIDENT = false>
+// MODE 0: persistent waves (chunks of many fills, lane refill).  MODE 1: the launch gives every wave at most one
+// fill (chunk <= 64 / G).  MODE 2: one fill and the SIMD to itself, recalculation constants resident in VGPRs.
+template <class Eqp, bool KIN, int MIN_WAVES_PER_SIMD, int MODE = 0>
 __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const DevParams* __restrict__ Pg, const long n, const BatchIn in,
                                                                          const uint32_t* __restrict__ warm, const BatchOut out, const long chunk,
                                                                          const int refill_t) {
@@ -442,13 +444,14 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
   Eqp eqp(qc_lds + STOCK_DOUBLES + lane);
   bool busy = false;  // group holds an unfinished robot
   QC_CLK_BEGIN();
-  UConst uc;  // RESIDENT: the recalculation's constants live in VGPRs for the whole kernel
-  if constexpr (RESIDENT) uc = load_uconst(*QC_PARAMS_HERE(Pg));
-  if constexpr (RESIDENT) {
-    // Small batch: the launch gives every wave at most one fill (chunk <= 64 / G) and the SIMD to itself, so the
-    // persistent-wave machinery (refill, stock cursors, per-recalculation result pushes) is dead weight on the
-    // serial chain that bounds the batch.  One fill, a divergent solve loop, one push, one flush.
+  if constexpr (MODE != 0) {
+    // One fill per wave: the persistent-wave machinery (refill, stock cursors, a result push after every
+    // recalculation) is dead weight on the serial chain that bounds such a batch.  One fill, a divergent solve
+    // loop, one push, one flush.
+    constexpr bool RESIDENT = MODE == 2;
     if (cursor >= end) return;
+    UConst uc;  // RESIDENT: the recalculation's constants live in VGPRs (no scalar load + wait per recalculation)
+    if constexpr (RESIDENT) uc = load_uconst(*QC_PARAMS_HERE(Pg));
     stock_n = restock<G, KIN>(Pg, in, warm, cursor, end, lane, member, sin);
     const int grp = lane / G;
     busy = grp < stock_n;
@@ -458,8 +461,12 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
     }
     QC_CLK(0, 2);
     while (busy) {
-      pin_uconst(uc);
-      busy = !L.iterate(uc, eqp);
+      if constexpr (RESIDENT) {
+        pin_uconst(uc);
+        busy = !L.iterate(uc, eqp);
+      } else {
+        busy = !L.iterate(*QC_PARAMS_HERE(Pg), eqp);
+      }
     }
     QC_CLK(7, 8);
     if (grp < stock_n) L.push_result(sout, grp);
@@ -503,13 +510,8 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
     if (busy) {
       asm volatile("; QC_ITER_BEGIN");
       QC_CLK(1, 2);
-      if constexpr (RESIDENT) {
-        pin_uconst(uc);
-        fin = L.iterate(uc, eqp);
-      } else {
-        CParams& P = *QC_PARAMS_HERE(Pg);
-        fin = L.iterate(P, eqp);
-      }
+      CParams& P = *QC_PARAMS_HERE(Pg);
+      fin = L.iterate(P, eqp);
       QC_CLK(7, 1);
       asm volatile("; QC_ITER_END");
     }
@@ -549,7 +551,7 @@ struct qc_handle {
   int refill_t;         // parked lanes that trigger a refill
   long chunk_override;  // development knob (QC_CHUNK)
   int group_override;   // development knob (QC_GROUP): lanes per robot
-  bool no_resident;     // development knob (QC_NO_RESIDENT): never take the one-wave-per-SIMD variant
+  bool no_single;       // development knob (QC_NO_SINGLE): never take the one-fill-per-wave variants
   // staging buffers for the host-pointer entry points
   void* stage;
   size_t stage_bytes;
@@ -792,7 +794,7 @@ int qc_create(const qc_params* p, int device, qc_handle** out) {
   if (const char* e = std::getenv("QC_WAVE_SLOTS")) h->wave_slots = std::atoi(e);
   h->group_override = 0;
   if (const char* e = std::getenv("QC_GROUP")) { const int g = std::atoi(e); if (g == 1 || g == 2 || g == 4) h->group_override = g; }
-  h->no_resident = std::getenv("QC_NO_RESIDENT") != nullptr;
+  h->no_single = std::getenv("QC_NO_SINGLE") != nullptr;
   if (hipSetDevice(device) != hipSuccess || hipMalloc((void**)&h->d_params, sizeof(qc::DevParams)) != hipSuccess ||
       hipMemcpy(h->d_params, &h->dp, sizeof(qc::DevParams), hipMemcpyHostToDevice) != hipSuccess) {
     delete h;
@@ -853,6 +855,7 @@ int qc_control_batch(qc_handle* h, size_t n, const qc_batch_in* in, const uint32
   if (h->chunk_override > 0) chunk = h->chunk_override;
   const unsigned blocks = (unsigned)(((long)n + chunk - 1) / chunk);
   const int refill_t = h->refill_t > 0 ? (h->refill_t + G - 1) / G : 1;
+  const bool single = chunk <= rpw && !h->no_single;  // every wave gets at most one fill
   const hipStream_t st = (hipStream_t)stream;
 #define QC_LAUNCH(EQP, MINW, LDS, ...)                                                                                               \
   do {                                                                                                                              \
@@ -862,8 +865,10 @@ int qc_control_batch(qc_handle* h, size_t n, const qc_batch_in* in, const uint32
   constexpr size_t kStock = qc::STOCK_DOUBLES * sizeof(double);
   if (!h->diag_w) QC_LAUNCH(qc::EqpDense, 1, kStock + 78 * 64 * sizeof(double));
   else if (!h->uniform) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<false, 1>), 2, kStock);
-  else if (G == 4 && chunk <= rpw && (long)blocks * 2 <= slots && !h->no_resident) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<true, 4>), 1, kStock, true);  // one wave per SIMD
+  else if (G == 4 && single && (long)blocks * 2 <= slots) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<true, 4>), 1, kStock, 2);  // one wave per SIMD
+  else if (G == 4 && single) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<true, 4>), 2, kStock, 1);
   else if (G == 4) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<true, 4>), 2, kStock);
+  else if (G == 2 && single) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<true, 2>), 2, kStock, 1);
   else if (G == 2) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<true, 2>), 2, kStock);
   else QC_LAUNCH(QC_COMMA(qc::EqpDiagW<true, 1>), 2, kStock);
 #undef QC_LAUNCH
