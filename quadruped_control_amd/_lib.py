@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libqc_balance.so")
+LIB_PATH = os.environ.get("QC_LIB_PATH") or os.path.join(_HERE, "libqc_balance.so")  # QC_LIB_PATH: development builds (tools/)
 
 QC_OK = 0
 STATUS_NAMES = {0: "solved", 1: "max_iter", 2: "infeasible", 3: "not_pd"}
