@@ -115,7 +115,8 @@ struct Lane {
       int ch = 0;
 #pragma unroll
       for (int i = 0; i < FPL; i++)
-        ch |= (int)clamp_foot(P.mu, lo(P, i), hi(P, i), fc[3 * i], fc[3 * i + 1], fc[3 * i + 2], Cc.sx[i], Cc.sy[i], Cc.sz[i]);
+        ch |= (int)clamp_foot(P.mu, lo(P, i), hi(P, i), C.sx[i], C.sy[i], C.sz[i], fc[3 * i], fc[3 * i + 1], fc[3 * i + 2], Cc.sx[i], Cc.sy[i],
+                              Cc.sz[i]);
       changed = group_or<G>(ch) != 0;
     }
     // (b) otherwise: ratio test over the faces outside the working set (tree min, face code in the low bits)
