@@ -5,8 +5,9 @@ import numpy as np, torch
 import quadruped_control_amd as q
 from quadruped_control_amd import workloads as W
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+cfg = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 P = q.cheetah_params(0.6)
-b = q.to_device(W.config2(n))
+b = q.to_device({2: W.config2, 3: W.config3}[cfg](n))
 def t(ctl, reps=100):
     out = ctl.control_batch(b)
     torch.cuda.synchronize()
