@@ -853,6 +853,10 @@ int qc_control_batch(qc_handle* h, size_t n, const qc_batch_in* in, const uint32
   const long slots = (long)h->wave_slots;
   long chunk = rpw;
   if ((long)n > rpw * slots) chunk = (((long)n + slots - 1) / slots + 15) / 16 * 16;
+  // The joint_q / joint_tau variants carry the kinematics through the persistent loop and spill 300-400 B per
+  // lane there; as one-fill workgroups (the hardware scheduler does the "refill") they stay at 68 B and win at
+  // every size (complete tick, 1 M robots: 1570 -> 941 us).  The plain path is the opposite (config 4: 124 vs 78 us).
+  if (kin && G > 1) chunk = rpw;
   if (h->chunk_override > 0) chunk = h->chunk_override;
   const unsigned blocks = (unsigned)(((long)n + chunk - 1) / chunk);
   const int refill_t = h->refill_t > 0 ? (h->refill_t + G - 1) / G : 1;
