@@ -322,9 +322,10 @@ int oracle_qp_solve(const double* H, const double* g, const double* C, const dou
       int r = idx[t];
       lam[r] = rhs[NV + t];
       double viol = (ws[r] == 1) ? -lam[r] : (ws[r] == -1 ? lam[r] : 0.0);
-      /* W ~ 1e-5 makes the primal very sensitive to a wrongly kept weakly-active row (a multiplier of
-       * -2e-7 moved a force by 3e-4 relative in testing), hence the tight relative threshold */
-      if (viol > 1e-13 * gs && (bland ? (worst < 0 || idx[t] < idx[worst]) : viol > wv)) { wv = viol; worst = t; }
+      /* W ~ 1e-5 (and smaller) makes the primal very sensitive to a wrongly kept weakly-active row: the objective
+       * curves only with 2w along it, so a multiplier of -t moves a force by t/(2w).  -2e-7 gave 3e-4 relative in
+       * testing, 1e-13*|c| still 7e-3 N on w = 2e-7 problems: the threshold sits just above the rounding noise. */
+      if (viol > 1e-15 * gs && (bland ? (worst < 0 || idx[t] < idx[worst]) : viol > wv)) { wv = viol; worst = t; }
     }
     if (worst < 0) {
       if (lam_out) memcpy(lam_out, lam, sizeof(lam));

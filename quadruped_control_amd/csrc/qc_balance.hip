@@ -781,7 +781,12 @@ int qc_create(const qc_params* p, int device, qc_handle** out) {
     sextic_basis(d.traj_basis);
   }
   d.stance_phase = 0.8 / (0.18 + 0.8);  // mit_cheetah_config.yaml:17-18
-  d.tol_d = 1e-12;  // relative to 1+|grad|_inf: W ~ 1e-5 makes the primal very sensitive to a wrongly kept weakly-active face
+  // Multiplier tolerance, relative to max(1, |grad|_inf).  It has to sit just above the rounding noise of the
+  // multipliers, not at a "reasonable" 1e-9: along a weakly active face the objective curves only with 2w, so a
+  // multiplier accepted at -tol*|g| leaves the force tol*|g|/(2w) away from the minimiser (w = 2.8e-7, |g| ~ 1e6:
+  // 1e-12 gave 0.2 N = 2e-3 relative in the parameter fuzz; 1e-13 ... 1e-15 all agree with the NNLS restatement
+  // and change neither the recalculation counts of 1 M robots nor anything else measurable).
+  d.tol_d = 1e-14;
   if (const char* e = std::getenv("QC_TOL_D")) d.tol_d = std::atof(e);  // development knob
   d.max_iter = p->max_iter > 0 ? p->max_iter : 200;
   if (const char* e = std::getenv("QC_PROBE_BATCH_LOAD")) if (e[0] == '1') d.max_iter = 0;  // bench.py --probe-batch-load
