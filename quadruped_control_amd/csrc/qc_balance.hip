@@ -92,16 +92,21 @@ struct Lane {
     return ok;
   }
 
-  // one working-set recalculation; returns true when the robot is finished
-  template <class PT>
+  // one working-set recalculation; returns true when the robot is finished.
+  // PHASE: MIXED = fresh and running robots share the wave (persistent waves with lane refill: one straight-line
+  // body, the clamp of the fresh ones behind a wave-uniform branch); FIRST / STEADY = the one-fill modes, where
+  // every robot of the wave is fresh in the first recalculation and none afterwards, so the first is peeled and
+  // the steady body carries no clamp, no fresh/running selects and no ratio test for nothing.
+  enum { MIXED = 0, FIRST = 1, STEADY = 2 };
+  template <int PHASE = MIXED, class PT>
   QC_DEV bool iterate(const PT& P, Eqp& eqp) {
     double fh[3 * FPL], g[3 * FPL];
     if (P.max_iter == 0) return true;  // measurement probe (QC_PROBE_BATCH_LOAD): load -> assemble -> store only
     iters++;
     const bool pd = eqp.solve(P, Wr, C, stance, foot0, fh, g);
-    const bool fresh = !have_f;
+    const bool fresh = PHASE == FIRST ? true : (PHASE == STEADY ? false : !have_f);
     have_f = true;
-    // (a) fresh robot: clamp f^ into the frusta.  Fresh robots exist only right
+    // (a) fresh robot: clamp f^ into the frusta.  In MIXED waves fresh robots exist only right
     // after a (re)fill, so the whole block sits behind a wave-uniform branch.
     double fc[3 * FPL];
     Cube<FPL> Cc;
@@ -111,7 +116,7 @@ struct Lane {
       fc[3 * i] = fh[3 * i]; fc[3 * i + 1] = fh[3 * i + 1]; fc[3 * i + 2] = fh[3 * i + 2];
       Cc.sx[i] = Cc.sy[i] = Cc.sz[i] = 0;
     }
-    if (__builtin_amdgcn_ballot_w64(fresh) != 0) {
+    if (PHASE == FIRST || (PHASE == MIXED && __builtin_amdgcn_ballot_w64(fresh) != 0)) {
       int ch = 0;
 #pragma unroll
       for (int i = 0; i < FPL; i++)
@@ -120,32 +125,39 @@ struct Lane {
       changed = group_or<G>(ch) != 0;
     }
     // (b) otherwise: ratio test over the faces outside the working set (tree min, face code in the low bits)
-    double cand[6 * FPL];
+    bool blocked = false;
+    int bcode = -1;
+    if constexpr (PHASE != FIRST) {
+      double cand[6 * FPL];
 #pragma unroll
-    for (int i = 0; i < FPL; i++) {
-      const double fx = f[3 * i], fy = f[3 * i + 1], fz = f[3 * i + 2];
-      const double dx = fh[3 * i] - fx, dy = fh[3 * i + 1] - fy, dz = fh[3 * i + 2] - fz;
-      const double m = P.mu * fz, md = P.mu * dz;
-      const bool zf = C.sz[i] == 0, xf = C.sx[i] == 0, yf = C.sy[i] == 0;
-      const int c0 = 6 * (foot0 + i);
-      cand[6 * i + 0] = step_cand(xf, m + fx, -dx - md, c0 + 0);     // X-
-      cand[6 * i + 1] = step_cand(xf, m - fx, dx - md, c0 + 1);      // X+
-      cand[6 * i + 2] = step_cand(yf, m + fy, -dy - md, c0 + 2);     // Y-
-      cand[6 * i + 3] = step_cand(yf, m - fy, dy - md, c0 + 3);      // Y+
-      cand[6 * i + 4] = step_cand(zf, fz - lo(P, i), -dz, c0 + 4);   // Z-
-      cand[6 * i + 5] = step_cand(zf, hi(P, i) - fz, dz, c0 + 5);    // Z+
+      for (int i = 0; i < FPL; i++) {
+        const double fx = f[3 * i], fy = f[3 * i + 1], fz = f[3 * i + 2];
+        const double dx = fh[3 * i] - fx, dy = fh[3 * i + 1] - fy, dz = fh[3 * i + 2] - fz;
+        const double m = P.mu * fz, md = P.mu * dz;
+        const bool zf = C.sz[i] == 0, xf = C.sx[i] == 0, yf = C.sy[i] == 0;
+        const int c0 = 6 * (foot0 + i);
+        cand[6 * i + 0] = step_cand(xf, m + fx, -dx - md, c0 + 0);     // X-
+        cand[6 * i + 1] = step_cand(xf, m - fx, dx - md, c0 + 1);      // X+
+        cand[6 * i + 2] = step_cand(yf, m + fy, -dy - md, c0 + 2);     // Y-
+        cand[6 * i + 3] = step_cand(yf, m - fy, dy - md, c0 + 3);      // Y+
+        cand[6 * i + 4] = step_cand(zf, fz - lo(P, i), -dz, c0 + 4);   // Z-
+        cand[6 * i + 5] = step_cand(zf, hi(P, i) - fz, dz, c0 + 5);    // Z+
+      }
+#pragma unroll
+      for (int w = 6 * FPL; w > 1; w = (w + 1) / 2)
+#pragma unroll
+        for (int k = 0; k < w / 2; k++) cand[k] = min_nn(cand[k], cand[k + (w + 1) / 2]);
+      const double amin = group_min<G>(cand[0]);
+      blocked = !fresh && (amin < 1.0e299);
+      bcode = blocked ? tag_code(amin) : -1;
+      // f <- f^ + (1 - alpha)(f - f^): exactly f^ for a full step
+      const double beta = blocked ? 1.0 - max_nn(amin, 0.0) : 0.0;
+#pragma unroll
+      for (int k = 0; k < 3 * FPL; k++) f[k] = fresh ? fc[k] : __builtin_fma(beta, f[k] - fh[k], fh[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 3 * FPL; k++) f[k] = fc[k];
     }
-#pragma unroll
-    for (int w = 6 * FPL; w > 1; w = (w + 1) / 2)
-#pragma unroll
-      for (int k = 0; k < w / 2; k++) cand[k] = min_nn(cand[k], cand[k + (w + 1) / 2]);
-    const double amin = group_min<G>(cand[0]);
-    const bool blocked = !fresh && (amin < 1.0e299);
-    const int bcode = blocked ? tag_code(amin) : -1;
-    // f <- f^ + (1 - alpha)(f - f^): exactly f^ for a full step
-    const double beta = blocked ? 1.0 - max_nn(amin, 0.0) : 0.0;
-#pragma unroll
-    for (int k = 0; k < 3 * FPL; k++) f[k] = fresh ? fc[k] : __builtin_fma(beta, f[k] - fh[k], fh[k]);
     // multiplier test, meaningful when f landed on f^
     const bool at_fh = fresh ? !changed : !blocked;
     int wcode;
@@ -461,12 +473,21 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
       eqp.setup(*QC_PARAMS_HERE(Pg), L.Wr);
     }
     QC_CLK(0, 2);
+    using LaneT = Lane<Eqp, KIN>;
+    if (busy) {  // every robot of a one-fill wave is fresh exactly once: the clamp step is peeled
+      if constexpr (RESIDENT) {
+        pin_uconst(uc);
+        busy = !L.template iterate<LaneT::FIRST>(uc, eqp);
+      } else {
+        busy = !L.template iterate<LaneT::FIRST>(*QC_PARAMS_HERE(Pg), eqp);
+      }
+    }
     while (busy) {
       if constexpr (RESIDENT) {
         pin_uconst(uc);
-        busy = !L.iterate(uc, eqp);
+        busy = !L.template iterate<LaneT::STEADY>(uc, eqp);
       } else {
-        busy = !L.iterate(*QC_PARAMS_HERE(Pg), eqp);
+        busy = !L.template iterate<LaneT::STEADY>(*QC_PARAMS_HERE(Pg), eqp);
       }
     }
     QC_CLK(7, 8);
