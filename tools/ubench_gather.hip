@@ -18,8 +18,10 @@ __device__ __forceinline__ void rows_via_lds(const double* __restrict__ a, long 
   const double2* src = reinterpret_cast<const double2*>(a + r0 * ROW);
   double2 t[PER];
 #pragma unroll
-  for (int j = 0; j < PER; j++)
-    if (lane + 64 * j < PIECES) t[j] = src[lane + 64 * j];
+  for (int j = 0; j < PER; j++) {
+    const int e = lane + 64 * j;
+    t[j] = src[e < PIECES ? e : PIECES - 1];
+  }
   double2* st = reinterpret_cast<double2*>(stage);
 #pragma unroll
   for (int j = 0; j < PER; j++)
@@ -38,8 +40,10 @@ __device__ __forceinline__ void pieces_load(const double* __restrict__ a, long r
   constexpr int PIECES = 32 * ROW, PER = (PIECES + 63) / 64;
   const double2* src = reinterpret_cast<const double2*>(a + r0 * ROW);
 #pragma unroll
-  for (int j = 0; j < PER; j++)
-    if (lane + 64 * j < PIECES) t[j] = src[lane + 64 * j];
+  for (int j = 0; j < PER; j++) {
+    const int e = lane + 64 * j;
+    t[j] = src[e < PIECES ? e : PIECES - 1];  // unconditional (clamped) so the pieces stay in registers
+  }
 }
 template <int ROW>
 __device__ __forceinline__ void pieces_to_lds(double* __restrict__ stage, int lane, const double2 (&t)[(32 * ROW + 63) / 64]) {
