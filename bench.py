@@ -114,7 +114,7 @@ def run_config(ctl, q, cfg, n, start, steps, warmup, dist=None, device=0, fused=
         out["joint_tau"] = torch.empty((n, 12), dtype=torch.float64, device=f"cuda:{device}")
     wall, evs = time_steps(ctl, dev_batch, warm, out, steps, warmup, dist)
     solved = int((out["status"] == 0).sum().item())
-    return dict(wall=wall, event_s=evs, solved=solved, n=n, batch=batch, warm=warm is not None)
+    return dict(wall=wall, event_s=evs, solved=solved, n=n, batch=batch, warm=warm is not None, out=out)
 
 
 def host_cores():
@@ -247,6 +247,9 @@ def main():
     ap.add_argument("--n", type=int, default=0, help="robots per GPU (default: the config's size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true", help="skip the informational runs of the other configs")
+    ap.add_argument("--gather-results", action="store_true",
+                    help="N > 1: after the timed region, all-gather the per-rank GRF blocks (result collection over xGMI, "
+                         "SURVEY 8e) and report the collective's time separately")
     ap.add_argument("--probe-batch-load", action="store_true",
                     help="time the load -> assemble -> store phase alone (no solver iterations) on 2,097,152 robots "
                          "(done by default together with the sweep)")
@@ -290,6 +293,14 @@ def main():
     wall, solved_total, total_robots = reduce_counters(dist, res["wall"], res["solved"], n,
                                                        device=f"cuda:{device}" if on_gpu else None)
 
+    gather_s = None
+    if dist is not None and args.gather_results:
+        from quadruped_control_amd.sharding import gather_results
+
+        shard = res["out"]["grf_body"] if on_gpu else res["out"]["grf_body"].cpu()
+        gathered, gather_s = gather_results(dist, shard)
+        assert gathered.shape[0] == total_robots
+
     if rank == 0:
         bytes_per = BYTES_PER_ROBOT_WARM if res["warm"] else BYTES_PER_ROBOT_COLD
         kernel_s = res["event_s"] / args.steps
@@ -316,6 +327,9 @@ def main():
                          "avg_kernel_us": kernel_s * 1e6,
                          "note": "latency/FP64-VALU bound active-set solve; traffic from the PMC pass is in profiles/"},
         }
+        if gather_s is not None:
+            line["result_gather"] = {"bytes_per_rank": n * 96, "seconds": gather_s, "GBs_per_rank": n * 96 * (world - 1) / gather_s / 1e9,
+                                     "what": "all_gather_into_tensor of the [n, 12] GRF blocks after the timed region (not part of value)"}
         tr = pmc_traffic(cfg, n)
         if tr is not None:
             line["roofline"]["traffic"] = tr[0]

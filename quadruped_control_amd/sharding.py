@@ -29,3 +29,23 @@ def reduce_counters(dist, wall_s, solved, robots, device=None):
     c = torch.tensor([int(solved), int(robots)], dtype=torch.int64, **kw)
     dist.all_reduce(c, op=dist.ReduceOp.SUM)
     return float(t.item()), int(c[0].item()), int(c[1].item())
+
+
+def gather_results(dist, grf_shard):
+    """Optional result collection: all-gather of the per-rank [n, 12] GRF blocks, outside the timed
+    hot path.  Returns (gathered tensor [world * n, 12], seconds).  RCCL over xGMI when the tensor lives on a GPU
+    and the backend is "nccl"; the CPU tests run it over gloo."""
+    import time
+
+    import torch
+
+    world = dist.get_world_size()
+    out = torch.empty((world * grf_shard.shape[0], grf_shard.shape[1]), dtype=grf_shard.dtype, device=grf_shard.device)
+    if grf_shard.is_cuda:
+        torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    dist.all_gather_into_tensor(out, grf_shard.contiguous())
+    if grf_shard.is_cuda:
+        torch.cuda.synchronize()
+    return out, time.perf_counter() - t0

@@ -57,3 +57,35 @@ def test_two_rank_sharding_gloo():
 
     full, st, _ = c_oracle.control_batch(R.cheetah_params(0.6), W.config5(n=n, start=0))
     np.testing.assert_array_equal(np.concatenate([g[2] for g in gathered]), full)
+
+
+def _gather_worker(rank, world, port, n, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from quadruped_control_amd.sharding import gather_results
+
+    shard = torch.arange(n * 12, dtype=torch.float64).reshape(n, 12) + 1000.0 * rank
+    out, secs = gather_results(dist, shard)
+    if rank == 0:
+        q.put((out.numpy(), secs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_result_gather_gloo():
+    """SURVEY 8e optional result collection: equal-sized per-rank GRF blocks all-gathered in rank order."""
+    n, world = 64, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out, secs = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    base = np.arange(n * 12, dtype=np.float64).reshape(n, 12)
+    np.testing.assert_array_equal(out, np.concatenate([base, base + 1000.0]))
+    assert secs >= 0.0

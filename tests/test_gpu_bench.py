@@ -44,7 +44,7 @@ def test_bench_two_ranks_torchrun(built):
     for the barrier / counter reduction instead of RCCL)."""
     env = dict(os.environ, QC_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "3"]
+           "--master-port", "29541", "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "3", "--gather-results"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _last_json(r.stdout)
@@ -52,3 +52,4 @@ def test_bench_two_ranks_torchrun(built):
     assert d["solved_fraction"] == 1.0 and d["value"] > 0
     assert abs(d["value"] - 8192 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     assert "cpu_baseline" not in d  # rank 0 at N = 1 only
+    assert d["result_gather"]["bytes_per_rank"] == 4096 * 96 and d["result_gather"]["seconds"] > 0
