@@ -209,6 +209,15 @@ def host_boundary(ctl, q):
     lat_c = (time.perf_counter() - t0) / reps
     res = {"config1_control_latency_us": lat * 1e6, "config1_qc_control_latency_us": lat_c * 1e6,
            "config1_grf_RL": [float(v) for v in f[names[0]]]}
+    exe = os.path.join(ROOT, "tests", "cpp", "adapter_test")  # built by __graft_entry__.build()
+    if os.path.exists(exe):
+        import subprocess
+
+        try:
+            out = subprocess.run([exe], capture_output=True, text=True, timeout=120).stdout
+            res["config1_cpp_adapter_latency_us"] = float(out.split("latency_us")[1].split()[0])
+        except Exception:
+            pass
     for cfg, n in ((2, CONFIG_N[2]), (4, CONFIG_N[4])):
         hb, _ = make_batch(cfg, n, 0)
         ctl.control_batch_host(hb)

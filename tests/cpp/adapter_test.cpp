@@ -1,6 +1,7 @@
 // Exercises the C++ BalanceController adapter exactly the way the reference's
 // commander node drives the original class (commander_node.cpp:289-338, 507-508).
 // Prints "OK" lines that tests/test_gpu_adapter.py parses.  Needs a GPU.
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <qc_balance_controller.hpp>
@@ -59,5 +60,14 @@ int main()
   copy_to_real_t(m, arr);
   if (arr[0] == 1.0 && arr[1] == 2.0 && arr[2] == 3.0 && arr[3] == 4.0) std::printf("OK copy_to_real_t\n");
   else { std::printf("FAIL copy_to_real_t\n"); fails++; }
+
+  // config 1 of the benchmark set: one robot per call through the class a ROS node links against
+  // (commander_node.cpp:507-508 does this at 300 Hz)
+  for (int i = 0; i < 50; i++) fm = balance_controller.control(Rwb, Rwb_d, x, zero, zero, x, zero, zero, feet);
+  const int reps = 2000;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < reps; i++) fm = balance_controller.control(Rwb, Rwb_d, x, zero, zero, x, zero, zero, feet);
+  const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps;
+  std::printf("latency_us %.2f (control() through the C++ adapter, %d calls, RL fz %.10f)\n", us, reps, fm.at("RL")(2));
   return fails;
 }
