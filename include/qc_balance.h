@@ -166,7 +166,10 @@ int qc_control_batch_host(qc_handle* h, size_t n, const qc_batch_in* in, const u
                           const qc_batch_out* out);
 
 /* One robot, host arguments laid out exactly like control()'s parameter list;
- * what the C++ BalanceController adapter (include/qc_balance_controller.hpp) calls. */
+ * what the C++ BalanceController adapter (include/qc_balance_controller.hpp) calls.
+ * Like the reference object (mutable SQProblem, balance_controller.hpp:161; init()/hotstart(),
+ * balance_controller.cpp:177-202) the handle keeps the working set of its previous successful call
+ * and starts the next one from it; the result is the same unique minimiser either way. */
 int qc_control(qc_handle* h, const double* Rwb, const double* Rwb_d, const double* x,
                const double* xdot, const double* w, const double* x_d, const double* xdot_d,
                const double* w_d, const double* feet, const uint8_t* stance, double* grf_body,

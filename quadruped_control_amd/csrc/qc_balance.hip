@@ -578,6 +578,8 @@ struct qc_handle {
   void* stage;
   size_t stage_bytes;
   void* pin;  // pinned host buffer the kernel reads/writes in place for small batches
+  uint32_t last_word;  // qc_control(): working set of the previous call (hot start)
+  bool has_last;
   hipStream_t stream;
 };
 
@@ -750,6 +752,8 @@ int qc_create(const qc_params* p, int device, qc_handle** out) {
   h->stage = nullptr;
   h->stage_bytes = 0;
   h->pin = nullptr;
+  h->last_word = 0;
+  h->has_last = false;
   h->stream = nullptr;
   h->d_params = nullptr;
   qc::DevParams& d = h->dp;
@@ -997,9 +1001,16 @@ int qc_control_batch_host(qc_handle* h, size_t n, const qc_batch_in* in, const u
 int qc_control(qc_handle* h, const double* Rwb, const double* Rwb_d, const double* x, const double* xdot,
                const double* w, const double* x_d, const double* xdot_d, const double* w_d, const double* feet,
                const uint8_t* stance, double* grf_body, int32_t* status) {
+  if (!h || !status) return fail(QC_ERR_INVALID, "qc_control: null argument");
   qc_batch_in in{Rwb, Rwb_d, x, xdot, w, x_d, xdot_d, w_d, feet, stance, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  qc_batch_out out{grf_body, status, nullptr, nullptr, nullptr};
-  return qc_control_batch_host(h, 1, &in, nullptr, &out);
+  // The handle remembers the working set of its previous call and starts from it - the per-instance hot-start
+  // memory of the reference's SQProblem (BC.hpp:161, BC.cpp:191-202).  Same minimiser either way (strictly convex).
+  uint32_t word_in = h->last_word, word_out = 0;
+  qc_batch_out out{grf_body, status, &word_out, nullptr, nullptr};
+  const int rc = qc_control_batch_host(h, 1, &in, h->has_last ? &word_in : nullptr, &out);
+  h->has_last = rc == QC_OK && *status == QC_SOLVED;
+  h->last_word = word_out;
+  return rc;
 }
 
 }  // extern "C"

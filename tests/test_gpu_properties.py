@@ -520,3 +520,31 @@ def test_rotation_log_branches(q):
     assert ambiguous.sum() == 12 and np.isfinite(o["grf_body"]).all()
     scale = np.maximum(1.0, np.abs(ref).max(axis=1, keepdims=True))
     assert np.max((np.abs(o["grf_body"] - ref) / scale)[ok & ~ambiguous]) < 1e-6
+
+
+def test_single_robot_calls_hot_start_from_the_previous_tick(q):
+    """qc_control keeps the working set of its previous call in the handle (the reference's per-object hot start,
+    balance_controller.cpp:191-202): a sequence of ticks through one controller gives the same forces as a fresh
+    controller per tick, also across contact changes and after a failed call."""
+    from quadruped_control_amd import workloads as W
+    from quadruped_control_amd.gait import LEG_NAMES, LegState
+
+    P = q.cheetah_params(0.6)
+    t0, t1 = W.config4(48)
+    seq = q.BalanceController.from_params(P)
+    worst = 0.0
+    for tick, b in enumerate((t0, t1, t0, t1)):
+        for i in range(48):
+            a = [b[k][i] for k in ("Rwb", "Rwb_d", "x", "xdot", "w", "x_d", "xdot_d", "w_d")]
+            feet = {nm: b["feet"][i].reshape(4, 3)[j] for j, nm in enumerate(LEG_NAMES)}
+            gait = {nm: ((LegState.stance if (i + tick + j) % 3 else LegState.swing), 0.0) for j, nm in enumerate(LEG_NAMES)}
+            got = seq.control(*a, feet, gait)
+            ref = q.BalanceController.from_params(P).control(*a, feet, gait) if i % 6 == 0 else None
+            if ref is not None:
+                assert set(got) == set(ref)
+                for nm in ref:
+                    worst = max(worst, float(np.abs(got[nm] - ref[nm]).max()))
+            if i == 20:  # a failed call (NaN state) must not poison the next one
+                bad = list(a); bad[2] = np.array([np.nan, 0.0, 0.26])
+                assert seq.control(*bad, feet, gait) == {}
+    assert worst < 1e-6
