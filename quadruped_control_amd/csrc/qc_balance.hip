@@ -578,6 +578,7 @@ struct qc_handle {
   void* stage;
   size_t stage_bytes;
   void* pin;  // pinned host buffer the kernel reads/writes in place for small batches
+  size_t pin_bytes;
   uint32_t last_word;  // qc_control(): working set of the previous call (hot start)
   bool has_last;
   hipStream_t stream;
@@ -752,6 +753,7 @@ int qc_create(const qc_params* p, int device, qc_handle** out) {
   h->stage = nullptr;
   h->stage_bytes = 0;
   h->pin = nullptr;
+  h->pin_bytes = 0;
   h->last_word = 0;
   h->has_last = false;
   h->stream = nullptr;
@@ -912,10 +914,10 @@ int qc_control_batch(qc_handle* h, size_t n, const qc_batch_in* in, const uint32
 }
 
 // host-pointer variant.  Large batches: one device staging allocation, H2D copies, kernel, D2H copies, sync.
-// Small batches (n <= kPinnedMaxN, the reference's own use: one robot per controller tick): the records are packed
+// Small batches (n <= kPinnedMaxN; the reference's own use is one robot per controller tick): the records are packed
 // into a pinned, device-visible host buffer that the kernel reads and writes in place over PCIe - one launch and one
 // stream synchronise instead of a dozen staged copies.
-static constexpr size_t kPinnedMaxN = 64;
+static constexpr size_t kPinnedMaxN = 8192;  // measured crossover with the staged copies: ~16 384 robots (config 2 records)
 int qc_control_batch_host(qc_handle* h, size_t n, const qc_batch_in* in, const uint32_t* warm, const qc_batch_out* out) {
   if (!h || !in || !out) return fail(QC_ERR_INVALID, "qc_control_batch_host: null argument");
   if (n == 0) return QC_OK;
@@ -931,7 +933,12 @@ int qc_control_batch_host(qc_handle* h, size_t n, const qc_batch_in* in, const u
   const size_t need = n * per + 512;
   char* base;
   if (pinned) {
-    if (!h->pin) QC_HIP(hipHostMalloc(&h->pin, kPinnedMaxN * per + 512, hipHostMallocDefault));
+    if (need > h->pin_bytes) {  // grows on demand: a handle that only ever sees one robot per call keeps ~2 KB pinned
+      if (h->pin) QC_HIP(hipHostFree(h->pin));
+      h->pin = nullptr; h->pin_bytes = 0;
+      QC_HIP(hipHostMalloc(&h->pin, need, hipHostMallocDefault));
+      h->pin_bytes = need;
+    }
     base = (char*)h->pin;
   } else {
     if (need > h->stage_bytes) {
@@ -983,7 +990,7 @@ int qc_control_batch_host(qc_handle* h, size_t n, const qc_batch_in* in, const u
   dout.iterations = out->iterations ? (int32_t*)carve(n * 4) : nullptr;
   dout.joint_tau = out->joint_tau ? (double*)carve(n * 12 * 8) : nullptr;
   QC_HIP(cerr);
-  if (off > (pinned ? kPinnedMaxN * per + 512 : h->stage_bytes)) return fail(QC_ERR_INVALID, "qc_control_batch_host: staging overflow");
+  if (off > (pinned ? h->pin_bytes : h->stage_bytes)) return fail(QC_ERR_INVALID, "qc_control_batch_host: staging overflow");
   int rc = qc_control_batch(h, n, &din, d_warm, &dout, h->stream);
   if (rc != QC_OK) return rc;
   if (pinned) QC_HIP(hipStreamSynchronize(h->stream));  // kernel-end release makes the in-place results visible

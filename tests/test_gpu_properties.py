@@ -455,7 +455,7 @@ def test_independent_handles_on_concurrent_streams(q):
 
 
 def test_small_batch_in_place_host_path_matches_staged(q):
-    """qc_control_batch_host serves n <= 64 from a pinned buffer the kernel reads/writes in place and larger
+    """qc_control_batch_host serves n <= 8192 from a pinned buffer the kernel reads/writes in place and larger
     batches through staged copies: the same robots must come back bit-identical either way, for the plain
     call and for the complete tick (swing state updated in place on the host)."""
     from tests.test_oracle_cpu import _planned_batch
@@ -463,20 +463,20 @@ def test_small_batch_in_place_host_path_matches_staged(q):
 
     P = q.cheetah_params(0.6)
     ctl = q.BalanceController.from_params(P)
-    big = W.config3(640)
+    big = W.config3(9000)  # staged
     ref = ctl.control_batch_host(big, want_active_set=True, want_iterations=True)
-    for lo, k in ((0, 1), (1, 7), (64, 64), (300, 33)):
+    for lo, k in ((0, 1), (1, 7), (64, 64), (300, 33), (700, 8192)):  # in place
         part = ctl.control_batch_host({f: v[lo:lo + k] for f, v in big.items()}, want_active_set=True, want_iterations=True)
         for name in ("grf_body", "status", "active_set", "iterations"):
             assert np.array_equal(part[name], ref[name][lo:lo + k]), (name, lo, k)
     warm = ctl.control_batch_host({f: v[:40] for f, v in big.items()}, warm=ref["active_set"][:40], want_iterations=True)
     assert np.abs(warm["grf_body"] - ref["grf_body"][:40]).max() < 1e-7 and warm["iterations"].max() <= 1
-    n = 640
+    n = 8500
     full_state, part_state = q.new_swing_states(n), q.new_swing_states(n)
     for tick in (0, 8, 16, 24):
         b = _planned_batch(n, tick)
-        o = ctl.control_batch_host(dict(b, swing_state=full_state), want_torques=True)
-        for lo, k in ((0, 64), (64, 1), (65, 50)):
+        o = ctl.control_batch_host(dict(b, swing_state=full_state), want_torques=True)  # staged
+        for lo, k in ((0, 64), (64, 1), (65, 50), (115, 8192), (8307, 193)):  # in place
             sub = {f: v[lo:lo + k] for f, v in b.items()}
             st = part_state[lo:lo + k].copy()
             p = ctl.control_batch_host(dict(sub, swing_state=st), want_torques=True)
