@@ -738,6 +738,7 @@ QC_DEV bool eqp_diagw(const PT& P, const Wrench<4 / G>& Wr, const Cube<4 / G>& C
 template <bool UNIFORM, int GROUP>
 struct EqpDiagW {
   static constexpr int G = GROUP;
+  static constexpr bool kRepackTail = UNIFORM && GROUP == 2;  // one-fill waves finish their stragglers 4 lanes per robot
   QC_DEV explicit EqpDiagW(double*) {}
   QC_DEV void setup(CParams&, const Wrench<4 / GROUP>&) {}
   template <class PT>
@@ -762,6 +763,7 @@ struct EqpDiagW {
 
 struct EqpDense {
   static constexpr int G = 1;
+  static constexpr bool kRepackTail = false;
   double* Qs;    // LDS base of this lane: element k at Qs[k * 64]
   double c[12];  // c = -2 A^T S b (BC.cpp:153)
 
