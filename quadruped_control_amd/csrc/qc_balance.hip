@@ -435,6 +435,69 @@ QC_DEV void flush_out(const DevParams* __restrict__ Pg, const BatchIn& in, const
   }
 }
 
+// Two lanes per robot: once at most 16 robots of a wave are still running they fit a 4-lanes-per-robot layout,
+// whose recalculation is 30 % shorter (620 vs 894 instructions) - and the wave waits for exactly these stragglers.
+// The running robots are re-packed through the (now idle) input stock and finish on the G = 4 body; `slot` is
+// where the robot's result goes in the output stock.  `bm` = ballot(busy), popcount <= 32.
+template <bool KIN, class Lane2>
+QC_DEV void finish_on_four_lanes(const DevParams* __restrict__ Pg, const Lane2& L, bool busy, unsigned long long bm, int slot, int member, int lane,
+                                 double* __restrict__ sin, double* __restrict__ sout) {
+  using Eqp4 = EqpDiagW<true, 4>;
+  using Lane4 = Lane<Eqp4, KIN>;
+  const int nb = __builtin_popcountll(bm) / 2;  // running robots
+  if (nb == 0) return;
+  constexpr int RS = 37;  // record stride in doubles (odd: the four lanes of a group read different banks)
+  const int rank2 = __builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0)) / 2;
+  __syncthreads();  // nobody reads the input stock any more
+  if (busy) {
+    double* rec = sin + rank2 * RS;
+    if (member == 0) {
+#pragma unroll
+      for (int k = 0; k < 6; k++) rec[k] = L.Wr.b[k];
+      rec[6] = __longlong_as_double(L.idx);
+      rec[7] = __longlong_as_double((long long)(((unsigned long long)(uint32_t)((L.iters << 8) | slot) << 32) | L.stance));
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int ft = 2 * member + i;
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        rec[8 + 3 * ft + k] = L.Wr.r[i][k];
+        rec[20 + 3 * ft + k] = L.f[3 * i + k];
+      }
+      rec[32 + ft] = __longlong_as_double((long long)encode_foot(L.C.sx[i], L.C.sy[i], L.C.sz[i]));
+    }
+  }
+  __syncthreads();
+  Lane4 L4;
+  Eqp4 eqp4(nullptr);
+  const int g4 = lane >> 2, j4 = lane & 3;
+  bool busy4 = g4 < nb;
+  int slot4 = 0;
+  if (busy4) {
+    const double* rec = sin + g4 * RS;
+#pragma unroll
+    for (int k = 0; k < 6; k++) L4.Wr.b[k] = rec[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      L4.Wr.r[0][k] = rec[8 + 3 * j4 + k];
+      L4.f[k] = rec[20 + 3 * j4 + k];
+    }
+    const uint32_t fw = (uint32_t)__double_as_longlong(rec[32 + j4]);
+    L4.C.sx[0] = dec2(fw); L4.C.sy[0] = dec2(fw >> 2); L4.C.sz[0] = dec2(fw >> 4);
+    L4.idx = __double_as_longlong(rec[6]);
+    const unsigned long long fl = (unsigned long long)__double_as_longlong(rec[7]);
+    L4.stance = (uint32_t)fl;
+    slot4 = (int)((fl >> 32) & 0xFFu);
+    L4.iters = (int)(fl >> 40);
+    L4.foot0 = j4;
+    L4.status = QC_MAX_ITER;
+    L4.have_f = true;
+  }
+  while (busy4) busy4 = !L4.template iterate<Lane4::STEADY>(*QC_PARAMS_HERE(Pg), eqp4);
+  if (g4 < nb) L4.push_result(sout, slot4);
+}
+
 // MODE 0: persistent waves (chunks of many fills, lane refill).  MODE 1: the launch gives every wave at most one
 // fill (chunk <= 64 / G).  MODE 2: one fill and the SIMD to itself, recalculation constants resident in VGPRs.
 template <class Eqp, bool KIN, int MIN_WAVES_PER_SIMD, int MODE = 0>
@@ -483,73 +546,13 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
       }
     }
     if constexpr (Eqp::kRepackTail) {
-      // Two lanes per robot: once at most 16 robots of the fill are still running they fit a 4-lanes-per-robot
-      // layout, whose recalculation is 30 % shorter (620 vs 894 instructions) - and the fill waits for exactly these
-      // stragglers.  The running robots are re-packed through the (now idle) input stock, the finished ones push
-      // their results, and the tail runs the G = 4 body.
-      using Eqp4 = EqpDiagW<true, 4>;
-      using Lane4 = Lane<Eqp4, KIN>;
       unsigned long long bm = __builtin_amdgcn_ballot_w64(busy);
       while (__builtin_popcountll(bm) > 32) {
         if (busy) busy = !L.template iterate<LaneT::STEADY>(*QC_PARAMS_HERE(Pg), eqp);
         bm = __builtin_amdgcn_ballot_w64(busy);
       }
-      const int nb = __builtin_popcountll(bm) / 2;  // running robots
-      if (nb > 0) {
-        constexpr int RS = 37;  // record stride in doubles (odd: the four lanes of a group read different banks)
-        const int rank2 = __builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0)) / 2;
-        if (busy) {
-          double* rec = sin + rank2 * RS;
-          if (member == 0) {
-#pragma unroll
-            for (int k = 0; k < 6; k++) rec[k] = L.Wr.b[k];
-            rec[6] = __longlong_as_double(L.idx);
-            rec[7] = __longlong_as_double((long long)(((unsigned long long)(uint32_t)((L.iters << 8) | grp) << 32) | L.stance));
-          }
-#pragma unroll
-          for (int i = 0; i < 2; i++) {
-            const int ft = 2 * member + i;
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-              rec[8 + 3 * ft + k] = L.Wr.r[i][k];
-              rec[20 + 3 * ft + k] = L.f[3 * i + k];
-            }
-            rec[32 + ft] = __longlong_as_double((long long)encode_foot(L.C.sx[i], L.C.sy[i], L.C.sz[i]));
-          }
-        } else if (grp < stock_n) {
-          L.push_result(sout, grp);
-        }
-        __syncthreads();
-        Lane4 L4;
-        Eqp4 eqp4(nullptr);
-        const int g4 = lane >> 2, j4 = lane & 3;
-        bool busy4 = g4 < nb;
-        int slot4 = 0;
-        if (busy4) {
-          const double* rec = sin + g4 * RS;
-#pragma unroll
-          for (int k = 0; k < 6; k++) L4.Wr.b[k] = rec[k];
-#pragma unroll
-          for (int k = 0; k < 3; k++) {
-            L4.Wr.r[0][k] = rec[8 + 3 * j4 + k];
-            L4.f[k] = rec[20 + 3 * j4 + k];
-          }
-          const uint32_t fw = (uint32_t)__double_as_longlong(rec[32 + j4]);
-          L4.C.sx[0] = dec2(fw); L4.C.sy[0] = dec2(fw >> 2); L4.C.sz[0] = dec2(fw >> 4);
-          L4.idx = __double_as_longlong(rec[6]);
-          const unsigned long long fl = (unsigned long long)__double_as_longlong(rec[7]);
-          L4.stance = (uint32_t)fl;
-          slot4 = (int)((fl >> 32) & 0xFFu);
-          L4.iters = (int)(fl >> 40);
-          L4.foot0 = j4;
-          L4.status = QC_MAX_ITER;
-          L4.have_f = true;
-        }
-        while (busy4) busy4 = !L4.template iterate<Lane4::STEADY>(*QC_PARAMS_HERE(Pg), eqp4);
-        if (g4 < nb) L4.push_result(sout, slot4);
-      } else if (grp < stock_n) {
-        L.push_result(sout, grp);
-      }
+      if (!busy && grp < stock_n) L.push_result(sout, grp);  // finished in the two-lane layout
+      finish_on_four_lanes<KIN>(Pg, L, busy, bm, grp, member, lane, sin, sout);
     } else {
       while (busy) {
         if constexpr (RESIDENT) {
