@@ -962,6 +962,10 @@ int qc_control_batch(qc_handle* h, size_t n, const qc_batch_in* in, const uint32
   // lane there; as one-fill workgroups (the hardware scheduler does the "refill") they stay at 68 B and win at
   // every size (complete tick, 1 M robots: 1570 -> 941 us).  The plain path is the opposite (config 4: 124 vs 78 us).
   if (kin && G > 1) chunk = rpw;
+  // Warm-started ticks finish in ~1 recalculation per robot: nothing for lane refill to balance, and up to six
+  // rounds of one-fill workgroups beat the persistent waves (262 144 robots: 53 vs 58 us; from ~450 k robots on
+  // the dense 64-robot assembly of the persistent kernel wins again).
+  if (warm && G == 2 && (long)n <= 6 * rpw * slots) chunk = rpw;
   if (h->chunk_override > 0) chunk = h->chunk_override;
   const unsigned blocks = (unsigned)(((long)n + chunk - 1) / chunk);
   const int refill_t = h->refill_t > 0 ? (h->refill_t + G - 1) / G : 1;
