@@ -7,7 +7,7 @@ from quadruped_control_amd import workloads as W
 from oracle import c_oracle as O
 from oracle import numpy_restatement as R
 want = set(int(a) for a in sys.argv[1:]) or {48, 95, 96}
-n = 2048
+n = int(os.environ.get("FUZZ_N", "2048"))
 rng = np.random.default_rng(77)
 FIELDS = ("Rwb", "Rwb_d", "x", "xdot", "w", "x_d", "xdot_d", "w_d", "feet")
 for trial in range(max(want) + 1):
