@@ -533,7 +533,7 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
     busy = grp < stock_n;
     if (busy) {
       L.load_from_stock(sin, grp, member);
-      eqp.setup(*QC_PARAMS_HERE(Pg), L.Wr);
+      eqp.setup(*QC_PARAMS_HERE(Pg), L.Wr, L.foot0);
     }
     QC_CLK(0, 2);
     using LaneT = Lane<Eqp, KIN>;
@@ -594,7 +594,7 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
       if (!busy && rank < take) {
         L.load_from_stock(sin, stock_next + rank, member);
         CParams& P = *QC_PARAMS_HERE(Pg);
-        eqp.setup(P, L.Wr);
+        eqp.setup(P, L.Wr, L.foot0);
         busy = true;
       }
       stock_next += take;
@@ -949,7 +949,7 @@ int qc_control_batch(qc_handle* h, size_t n, const qc_batch_in* in, const uint32
   // Batches larger than the chip holds at once run as persistent waves, each
   // walking a contiguous chunk with lane refill.
   int G = 1;
-  if (h->diag_w && h->uniform) {
+  if (h->diag_w) {
     const long lanes = (long)h->wave_slots * 64;
     G = (long)n * 4 <= lanes ? 4 : 2;
     if (h->group_override) G = h->group_override;
@@ -978,6 +978,10 @@ int qc_control_batch(qc_handle* h, size_t n, const qc_batch_in* in, const uint32
   } while (0)
   constexpr size_t kStock = qc::STOCK_DOUBLES * sizeof(double);
   if (!h->diag_w) QC_LAUNCH(qc::EqpDense, 1, kStock + 78 * 64 * sizeof(double));
+  else if (!h->uniform && G == 4 && single) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<false, 4>), 2, kStock, 1);
+  else if (!h->uniform && G == 4) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<false, 4>), 2, kStock);
+  else if (!h->uniform && G == 2 && single) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<false, 2>), 2, kStock, 1);
+  else if (!h->uniform && G == 2) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<false, 2>), 2, kStock);
   else if (!h->uniform) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<false, 1>), 2, kStock);
   else if (G == 4 && single && (long)blocks * 2 <= slots) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<true, 4>), 1, kStock, 2);  // one wave per SIMD
   else if (G == 4 && single) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<true, 4>), 2, kStock, 1);

@@ -566,10 +566,25 @@ struct FootCoef {
   double mx, my, fzfix, ix, iy, iz;
 };
 // UNIFORM = (S diagonal, W = w*I): a handful of scalar constants instead of
-// ~60, so they all stay in SGPRs.  The per-foot constant tables of the general
-// form are indexed with the compile-time foot number, hence G = 1 only there.
+// ~60, so they all stay in SGPRs.  The general diagonal-W form takes the weights of
+// the foot from a FootW: built from the constant tables with the compile-time foot
+// number when a lane owns all four feet (G = 1: scalar operands), or loaded once per
+// robot into the lane's registers when a lane owns the feet foot0 ... (lane groups).
+struct FootW {
+  double inv_wx, inv_wy, inv_bz[4], w[3];
+};
+QC_DEV FootW foot_weights(CParams& P, int foot) {
+  FootW t;
+  t.inv_wx = P.inv_wx[foot];
+  t.inv_wy = P.inv_wy[foot];
+#pragma unroll
+  for (int k = 0; k < 4; k++) t.inv_bz[k] = P.inv_bz[4 * foot + k];
+#pragma unroll
+  for (int k = 0; k < 3; k++) t.w[k] = P.w[3 * foot + k];
+  return t;
+}
 template <bool UNIFORM, class PT>
-QC_DEV FootCoef foot_coef(const PT& P, int sx, int sy, int sz, bool st, int foot) {
+QC_DEV FootCoef foot_coef(const PT& P, const FootW& fw, int sx, int sy, int sz, bool st) {
   FootCoef k;
   k.mx = P.mu * (double)sx;
   k.my = P.mu * (double)sy;
@@ -581,21 +596,27 @@ QC_DEV FootCoef foot_coef(const PT& P, int sx, int sy, int sz, bool st, int foot
     const double b0 = sy != 0 ? P.inv_bz_u[1] : P.inv_bz_u[0];
     k.iz = (st && sz == 0) ? (sx != 0 ? b1 : b0) : 0.0;
   } else {
-    k.ix = (st && sx == 0) ? P.inv_wx[foot] : 0.0;
-    k.iy = (st && sy == 0) ? P.inv_wy[foot] : 0.0;
-    const double b0 = sy != 0 ? P.inv_bz[4 * foot + 1] : P.inv_bz[4 * foot];
-    const double b1 = sy != 0 ? P.inv_bz[4 * foot + 3] : P.inv_bz[4 * foot + 2];
+    k.ix = (st && sx == 0) ? fw.inv_wx : 0.0;
+    k.iy = (st && sy == 0) ? fw.inv_wy : 0.0;
+    const double b0 = sy != 0 ? fw.inv_bz[1] : fw.inv_bz[0];
+    const double b1 = sy != 0 ? fw.inv_bz[3] : fw.inv_bz[2];
     k.iz = (st && sz == 0) ? (sx != 0 ? b1 : b0) : 0.0;
   }
   return k;
 }
 
 // `stance` = 4-bit mask of the robot, `foot0` = first foot of this lane.
+// `lane_w`: the lane's foot weights (general form with lane groups; ignored otherwise).
 template <bool UNIFORM, int G, class PT>
-QC_DEV bool eqp_diagw(const PT& P, const Wrench<4 / G>& Wr, const Cube<4 / G>& C, uint32_t stance, int foot0, double (&f)[12 / G],
-                      double (&g)[12 / G]) {
+QC_DEV bool eqp_diagw(const PT& P, const FootW (&lane_w)[4 / G], const Wrench<4 / G>& Wr, const Cube<4 / G>& C, uint32_t stance, int foot0,
+                      double (&f)[12 / G], double (&g)[12 / G]) {
   constexpr int FPL = 4 / G;
-  static_assert(UNIFORM || G == 1, "per-foot weight tables need compile-time foot numbers");
+  // weights of foot i of this lane: compile-time table entries when the lane owns all feet, its registers otherwise
+  auto weights = [&](int i) -> FootW {
+    if constexpr (UNIFORM) return FootW{};
+    else if constexpr (G == 1) return foot_weights(P, i);
+    else return lane_w[i];
+  };
   double M[21];
   // packed lower triangle index r*(r+1)/2 + c
 #define MI(r, c) ((r) * ((r) + 1) / 2 + (c))
@@ -614,7 +635,8 @@ QC_DEV bool eqp_diagw(const PT& P, const Wrench<4 / G>& Wr, const Cube<4 / G>& C
 #pragma unroll
   for (int i = 0; i < FPL; i++) {
     const bool st = (stance >> (foot0 + i)) & 1u;
-    const FootCoef k = foot_coef<UNIFORM>(P, C.sx[i], C.sy[i], C.sz[i], st, G == 1 ? i : 0);
+    const FootW fwt = weights(i);
+    const FootCoef k = foot_coef<UNIFORM>(P, fwt, C.sx[i], C.sy[i], C.sz[i], st);
     if (KEEP) kc[i] = k;
     const double rx = Wr.r[i][0], ry = Wr.r[i][1], rz = Wr.r[i][2];
     double q[6];
@@ -711,7 +733,8 @@ QC_DEV bool eqp_diagw(const PT& P, const Wrench<4 / G>& Wr, const Cube<4 / G>& C
 #pragma unroll
   for (int i = 0; i < FPL; i++) {
     const bool st = (stance >> (foot0 + i)) & 1u;
-    const FootCoef k = KEEP ? kc[i] : foot_coef<UNIFORM>(P, C.sx[i], C.sy[i], C.sz[i], st, G == 1 ? i : 0);
+    const FootW fwt = weights(i);
+    const FootCoef k = KEEP ? kc[i] : foot_coef<UNIFORM>(P, fwt, C.sx[i], C.sy[i], C.sz[i], st);
     const double rx = Wr.r[i][0], ry = Wr.r[i][1], rz = Wr.r[i][2];
     const double ax = v[0] + v[4] * rz - v[5] * ry;  // (A_i^T v)_x
     const double ay = v[1] + v[5] * rx - v[3] * rz;
@@ -723,7 +746,7 @@ QC_DEV bool eqp_diagw(const PT& P, const Wrench<4 / G>& Wr, const Cube<4 / G>& C
     f[3 * i] = fx; f[3 * i + 1] = fy; f[3 * i + 2] = fz;
     double wx, wy, wz;
     if constexpr (UNIFORM) wx = wy = wz = P.w_u;
-    else { wx = P.w[3 * (G == 1 ? i : 0)]; wy = P.w[3 * (G == 1 ? i : 0) + 1]; wz = P.w[3 * (G == 1 ? i : 0) + 2]; }
+    else { wx = fwt.w[0]; wy = fwt.w[1]; wz = fwt.w[2]; }
     g[3 * i] = 2.0 * __builtin_fma(wx, fx, ax);
     g[3 * i + 1] = 2.0 * __builtin_fma(wy, fy, ay);
     g[3 * i + 2] = 2.0 * __builtin_fma(wz, fz, az);
@@ -739,12 +762,19 @@ template <bool UNIFORM, int GROUP>
 struct EqpDiagW {
   static constexpr int G = GROUP;
   static constexpr bool kRepackTail = UNIFORM && GROUP == 2;  // one-fill waves finish their stragglers 4 lanes per robot
+  FootW lane_w[4 / GROUP];  // general form with lane groups: the weights of this lane's feet (dead otherwise)
   QC_DEV explicit EqpDiagW(double*) {}
-  QC_DEV void setup(CParams&, const Wrench<4 / GROUP>&) {}
+  // called when the lane takes a robot; `foot0` = first foot of the lane
+  QC_DEV void setup(CParams& P, const Wrench<4 / GROUP>&, int foot0) {
+    if constexpr (!UNIFORM && GROUP > 1) {
+#pragma unroll
+      for (int i = 0; i < 4 / GROUP; i++) lane_w[i] = foot_weights(P, foot0 + i);
+    }
+  }
   template <class PT>
   QC_DEV bool solve(const PT& P, const Wrench<4 / GROUP>& Wr, const Cube<4 / GROUP>& C, uint32_t stance, int foot0, double (&f)[12 / GROUP],
                     double (&g)[12 / GROUP]) {
-    return eqp_diagw<UNIFORM, GROUP>(P, Wr, C, stance, foot0, f, g);
+    return eqp_diagw<UNIFORM, GROUP>(P, lane_w, Wr, C, stance, foot0, f, g);
   }
 };
 
@@ -772,7 +802,7 @@ struct EqpDense {
   QC_DEV explicit EqpDense(double* lds_lane) : Qs(lds_lane) {}
 
   // assemble Q (into LDS) and c for the robot this lane just fetched
-  QC_DEV void setup(CParams& P, const Wrench<4>& Wr) {
+  QC_DEV void setup(CParams& P, const Wrench<4>& Wr, int) {
     double Sb[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) {
