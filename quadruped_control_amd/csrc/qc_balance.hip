@@ -439,10 +439,10 @@ QC_DEV void flush_out(const DevParams* __restrict__ Pg, const BatchIn& in, const
 // whose recalculation is 30 % shorter (620 vs 894 instructions) - and the wave waits for exactly these stragglers.
 // The running robots are re-packed through the (now idle) input stock and finish on the G = 4 body; `slot` is
 // where the robot's result goes in the output stock.  `bm` = ballot(busy), popcount <= 32.
-template <bool KIN, class Lane2>
+template <bool KIN, bool UNIFORM, class Lane2>
 QC_DEV void finish_on_four_lanes(const DevParams* __restrict__ Pg, const Lane2& L, bool busy, unsigned long long bm, int slot, int member, int lane,
                                  double* __restrict__ sin, double* __restrict__ sout) {
-  using Eqp4 = EqpDiagW<true, 4>;
+  using Eqp4 = EqpDiagW<UNIFORM, 4>;
   using Lane4 = Lane<Eqp4, KIN>;
   const int nb = __builtin_popcountll(bm) / 2;  // running robots
   if (nb == 0) return;
@@ -493,6 +493,7 @@ QC_DEV void finish_on_four_lanes(const DevParams* __restrict__ Pg, const Lane2& 
     L4.foot0 = j4;
     L4.status = QC_MAX_ITER;
     L4.have_f = true;
+    eqp4.setup(*QC_PARAMS_HERE(Pg), L4.Wr, j4);
   }
   while (busy4) busy4 = !L4.template iterate<Lane4::STEADY>(*QC_PARAMS_HERE(Pg), eqp4);
   if (g4 < nb) L4.push_result(sout, slot4);
@@ -552,7 +553,7 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
         bm = __builtin_amdgcn_ballot_w64(busy);
       }
       if (!busy && grp < stock_n) L.push_result(sout, grp);  // finished in the two-lane layout
-      finish_on_four_lanes<KIN>(Pg, L, busy, bm, grp, member, lane, sin, sout);
+      finish_on_four_lanes<KIN, Eqp::kUniform>(Pg, L, busy, bm, grp, member, lane, sin, sout);
     } else {
       while (busy) {
         if constexpr (RESIDENT) {

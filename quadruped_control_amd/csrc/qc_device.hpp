@@ -761,7 +761,8 @@ QC_DEV bool eqp_diagw(const PT& P, const FootW (&lane_w)[4 / G], const Wrench<4 
 template <bool UNIFORM, int GROUP>
 struct EqpDiagW {
   static constexpr int G = GROUP;
-  static constexpr bool kRepackTail = UNIFORM && GROUP == 2;  // one-fill waves finish their stragglers 4 lanes per robot
+  static constexpr bool kUniform = UNIFORM;
+  static constexpr bool kRepackTail = GROUP == 2;  // one-fill waves finish their stragglers 4 lanes per robot
   FootW lane_w[4 / GROUP];  // general form with lane groups: the weights of this lane's feet (dead otherwise)
   QC_DEV explicit EqpDiagW(double*) {}
   // called when the lane takes a robot; `foot0` = first foot of the lane
