@@ -328,6 +328,13 @@ int oracle_qp_solve(const double* H, const double* g, const double* C, const dou
       if (viol > 1e-15 * gs && (bland ? (worst < 0 || idx[t] < idx[worst]) : viol > wv)) { wv = viol; worst = t; }
     }
     if (worst < 0) {
+      /* a checker must not certify an infeasible point: nearly parallel rows (mu -> 0) can defeat the
+       * dependent-row logic above; report failure instead of a wrong ORACLE_OK */
+      for (int r = 0; r < NC; r++) {
+        double cf = 0.0;
+        for (int k = 0; k < NV; k++) cf += C[r * NV + k] * f[k];
+        if (cf > ub[r] + 1e-7 * (1 + fabs(ub[r])) || cf < lb[r] - 1e-7 * (1 + fabs(lb[r]))) return ORACLE_MAX_ITER;
+      }
       if (lam_out) memcpy(lam_out, lam, sizeof(lam));
       if (iters_out) *iters_out = it + 1;
       return ORACLE_OK;
