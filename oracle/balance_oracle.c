@@ -375,7 +375,14 @@ int oracle_control(const oracle_params* P, const double* Rwb, const double* Rwb_
                    double* grf_body, double* f_world, int* iters) {
   double H[NV * NV], g[NV], C[NC * NV], lb[NC], ub[NC], fw[NV];
   oracle_assemble(P, Rwb, Rwb_d, x, xdot, w, x_d, xdot_d, w_d, feet, stance, H, g, C, lb, ub, 0, 0);
-  int st = oracle_qp_solve(H, g, C, lb, ub, P->max_iter > 0 ? P->max_iter : 200, fw, 0, iters);
+  /* non-finite inputs poison H or g: qpOASES cannot return SUCCESSFUL_RETURN on such data, i.e. the reference
+   * ends with an empty ForceMap (BC.cpp:182-216); report it as a failed instance instead of iterating on NaNs */
+  int finite = 1;
+  for (int k = 0; k < NV * NV; k++) finite &= isfinite(H[k]) ? 1 : 0;
+  for (int k = 0; k < NV; k++) finite &= isfinite(g[k]) ? 1 : 0;
+  for (int k = 0; k < 9; k++) finite &= isfinite(Rwb[k]) ? 1 : 0;
+  int st = finite ? oracle_qp_solve(H, g, C, lb, ub, P->max_iter > 0 ? P->max_iter : 200, fw, 0, iters) : ORACLE_NOT_PD;
+  if (!finite && iters) *iters = 0;
   for (int k = 0; k < NV; k++) grf_body[k] = 0.0;
   if (f_world) for (int k = 0; k < NV; k++) f_world[k] = (st == ORACLE_OK) ? fw[k] : 0.0;
   if (st != ORACLE_OK) return st; /* reference: empty ForceMap, BC.cpp:182-216 */

@@ -548,3 +548,38 @@ def test_single_robot_calls_hot_start_from_the_previous_tick(q):
                 bad = list(a); bad[2] = np.array([np.nan, 0.0, 0.26])
                 assert seq.control(*bad, feet, gait) == {}
     assert worst < 1e-6
+
+
+def test_unphysical_inputs_match_the_oracle(q):
+    """The reference (Release build) checks nothing about its inputs; whatever arithmetic it would do on garbage,
+    device and oracle do the same: non-orthonormal / random 'rotations', feet at the COM, four coincident feet,
+    kilometre legs, denormals, and non-finite states (a failed instance on both sides, never NaN forces)."""
+    from oracle import c_oracle as O
+    from quadruped_control_amd import workloads as W
+
+    P = q.cheetah_params(0.6)
+    ctl = q.BalanceController.from_params(P)
+    rng = np.random.default_rng(5)
+    n = 2048
+    b = W.config3(n)
+    cases = {}
+    cases["scaled"] = dict(b, Rwb=np.ascontiguousarray(b["Rwb"] * rng.uniform(0.5, 1.5, (n, 1))))
+    cases["random"] = dict(b, Rwb=np.ascontiguousarray(rng.normal(size=(n, 9))), Rwb_d=np.ascontiguousarray(rng.normal(size=(n, 9))))
+    cases["at_com"] = dict(b, feet=np.zeros_like(b["feet"]))
+    f = b["feet"].copy().reshape(n, 4, 3); f[:, 1:] = f[:, :1]
+    cases["coincident"] = dict(b, feet=np.ascontiguousarray(f.reshape(n, 12)))
+    cases["km_legs"] = dict(b, feet=np.ascontiguousarray(b["feet"] * 1e3))
+    cases["denormal"] = dict(b, x=np.ascontiguousarray(b["x"] + 1e-310))
+    x = b["x"].copy(); x[::7, 0] = np.inf; x[3::7, 2] = np.nan
+    cases["nonfinite"] = dict(b, x=x)
+    for name, c in cases.items():
+        o = ctl.control_batch_host(c)
+        ref, st, _ = O.control_batch(P, c, threads=8)
+        assert np.array_equal(o["status"], st), name
+        assert np.isfinite(o["grf_body"]).all(), name
+        ok = st == 0
+        scale = np.maximum(1.0, np.abs(ref).max(axis=1, keepdims=True))
+        tol = 1e-4 if name == "km_legs" else 1e-6  # km legs: cond(A) ~ 1e6, still inside the north-star bar
+        assert np.max((np.abs(o["grf_body"] - ref) / scale)[ok]) < tol, name
+        assert np.all(o["grf_body"][~ok] == 0.0), name
+    assert (ctl.control_batch_host(cases["nonfinite"])["status"][::7] == 3).all()
