@@ -392,7 +392,12 @@ QC_DEV void store_from_stock(CParams& P, const BatchIn& in, const BatchOut& out,
       }
       double* to = out.joint_tau + 12 * idx + 3 * (foot0 + i);
 #pragma unroll
-      for (int r = 0; r < 3; r++) to[r] = emit ? fmin(fmax(tau[r], P.tau_min), P.tau_max) : 0.0;
+      for (int r = 0; r < 3; r++) {
+        // arma::clamp (commander_node.cpp:526) is two compares: a NaN torque (NaN joint state) stays NaN, as in
+        // the reference, instead of turning into a full-scale command the way fmin(fmax()) would make it
+        const double t = tau[r];
+        to[r] = emit ? (t < P.tau_min ? P.tau_min : (t > P.tau_max ? P.tau_max : t)) : 0.0;
+      }
     }
   }
   if (member == 0) {

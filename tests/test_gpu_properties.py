@@ -583,3 +583,25 @@ def test_unphysical_inputs_match_the_oracle(q):
         assert np.max((np.abs(o["grf_body"] - ref) / scale)[ok]) < tol, name
         assert np.all(o["grf_body"][~ok] == 0.0), name
     assert (ctl.control_batch_host(cases["nonfinite"])["status"][::7] == 3).all()
+
+
+def test_non_finite_joint_states_in_the_widened_tick(q):
+    """NaN / inf joint angles or swing references: the QP instance fails on both sides (status 3, zero GRFs) and
+    the swing-leg torques of such legs come out NaN exactly where the reference's arithmetic (two-compare
+    arma::clamp, commander_node.cpp:526) leaves them NaN - never as a clamped full-scale command."""
+    from oracle import c_oracle as O
+    from quadruped_control_amd import workloads as W
+
+    P = q.cheetah_params(0.6)
+    n = 1024
+    b = W.with_swing_references(W.with_joint_angles(W.config3(n)))
+    jq = b["joint_q"].copy(); jq[::5, 4] = np.nan; jq[2::5, 0] = np.inf
+    sp = b["swing_pos"].copy(); sp[1::9, 7] = np.nan
+    b = dict(b, joint_q=jq, swing_pos=sp)
+    o = q.BalanceController.from_params(P).control_batch_host(b, want_torques=True)
+    ref = O.tick_swing_batch(P, b, threads=8)
+    assert np.array_equal(o["status"], ref["status"]) and (o["status"][::5] == 3).all()
+    assert np.isfinite(o["grf_body"]).all() and np.all(o["grf_body"][o["status"] != 0] == 0.0)
+    assert np.array_equal(np.isnan(o["joint_tau"]), np.isnan(ref["joint_tau"])) and np.isnan(o["joint_tau"]).any()
+    m = ~np.isnan(ref["joint_tau"])
+    assert np.abs(o["joint_tau"] - ref["joint_tau"])[m].max() < 2e-5
