@@ -383,7 +383,8 @@ QC_DEV void plan_foothold(CParams& P, int leg, const double (&R)[9], const doubl
 QC_DEV void track_swing(CParams& P, double phase, const double (&p0)[3], const double (&pf)[3], double (&pos)[3], double (&vel)[3]) {
   const double duty = P.t_stance / (P.t_swing + P.t_stance);  // stance_phase_, trajectory.cpp:303
   const double slope = 1.0 / (1.0 - duty), yint = 1.0 - slope; // :304-305
-  const double t = fmin(fmax(slope * phase + yint, 0.0), 1.0);  // :369
+  const double u = slope * phase + yint;
+  const double t = u < 0.0 ? 0.0 : (1.0 < u ? 1.0 : u);  // std::clamp, :369 (two compares: a NaN phase stays NaN)
   double h[3] = {0.0, 0.0, 0.0}, dh[3] = {0.0, 0.0, 0.0};
   double tp = 1.0, tpm = 0.0;  // t^j and j t^(j-1)
 #pragma unroll

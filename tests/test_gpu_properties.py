@@ -605,3 +605,36 @@ def test_non_finite_joint_states_in_the_widened_tick(q):
     assert np.array_equal(np.isnan(o["joint_tau"]), np.isnan(ref["joint_tau"])) and np.isnan(o["joint_tau"]).any()
     m = ~np.isnan(ref["joint_tau"])
     assert np.abs(o["joint_tau"] - ref["joint_tau"])[m].max() < 2e-5
+
+
+def test_non_finite_states_in_the_stateful_tick(q):
+    """NaN velocities / inf positions / NaN gait phases over a sequence of planned ticks: the carried swing state,
+    the statuses and the NaN pattern of the torques follow the oracle (std::clamp of the trajectory time,
+    trajectory.cpp:369, keeps a NaN phase NaN)."""
+    from oracle import c_oracle as O
+    from tests.test_oracle_cpu import _planned_batch
+
+    P = q.cheetah_params(0.6)
+    ctl = q.BalanceController.from_params(P)
+    n = 512
+    dev, ref = q.new_swing_states(n), O.new_swing_states(n)
+    saw_nan = False
+    for tick in range(0, 120, 12):
+        b = _planned_batch(n, tick)
+        xd = b["xdot"].copy(); xd[::11, 0] = np.nan
+        xx = b["x"].copy(); xx[5::13, 1] = np.inf
+        gp = b["gait_phase"].copy(); gp[7::17, 2] = np.nan
+        b = dict(b, xdot=xd, x=xx, gait_phase=gp)
+        o = ctl.control_batch_host(dict(b, swing_state=dev), want_torques=True)
+        r = O.tick_planned_batch(P, b, ref, threads=8)
+        assert np.array_equal(o["status"], r["status"])
+        assert np.array_equal(dev["leg_state"], ref["leg_state"]) and np.array_equal(dev["has_traj"], ref["has_traj"])
+        m = ref["has_traj"].repeat(3, axis=1) == 1
+        for k in ("p_start", "p_final"):
+            assert np.array_equal(np.isnan(dev[k][m]), np.isnan(ref[k][m]))
+            assert np.nanmax(np.abs(dev[k][m] - ref[k][m])) < 1e-9
+        assert np.array_equal(np.isnan(o["joint_tau"]), np.isnan(r["joint_tau"]))
+        fin = ~np.isnan(r["joint_tau"])
+        assert np.abs(o["joint_tau"] - r["joint_tau"])[fin].max() < 2e-5
+        saw_nan |= bool(np.isnan(o["joint_tau"]).any())
+    assert saw_nan
