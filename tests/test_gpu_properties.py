@@ -266,6 +266,10 @@ def test_on_device_contact_rule(q):
     phases[50:100, 1] = duty[50:100]
     phases[100:150, 2] = duty[100:150] + 5e-13
     phases[150:200, 3] = duty[150:200] + 1e-9
+    phases[200:220, 0] = -5e-13                # inside the slack below 0: stance (gait.cpp:125-134 via almost_equal)
+    phases[220:240, 1] = -0.3                  # out of range either way: swing
+    phases[240:260, 2] = 1.2
+    phases[260:280, 3] = np.nan                # every comparison false: swing
     stance = leg_state_from_phase(phases, duty[:, None])
     ctl = q.BalanceController.from_params(P)
     ref = ctl.control_batch_host(dict(b, stance=stance))
