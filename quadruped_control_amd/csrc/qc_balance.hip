@@ -49,6 +49,7 @@ template <class Eqp, bool KIN>
 struct Lane {
   static constexpr int G = Eqp::G;
   static constexpr int FPL = 4 / G;  // feet per lane
+  static constexpr bool S = Eqp::kStrided;
   Wrench<FPL> Wr;
   Cube<FPL> C;
   double f[3 * FPL];
@@ -70,7 +71,7 @@ struct Lane {
     double gs = 1.0;
 #pragma unroll
     for (int k = 0; k < 3 * FPL; k++) gs = max_abs_nn(gs, g[k]);
-    gs = group_max<G>(gs);
+    gs = group_max<G, S>(gs);
     double cand[3 * FPL];
 #pragma unroll
     for (int i = 0; i < FPL; i++) {
@@ -86,7 +87,7 @@ struct Lane {
     for (int w = 3 * FPL; w > 1; w = (w + 1) / 2)
 #pragma unroll
       for (int k = 0; k < w / 2; k++) cand[k] = min_nn(cand[k], cand[k + (w + 1) / 2]);
-    const double worst = group_min<G>(cand[0]);
+    const double worst = group_min<G, S>(cand[0]);
     const bool ok = !(worst < -P.tol_d * gs);
     wcode = ok ? -1 : tag_code(worst);
     return ok;
@@ -122,7 +123,7 @@ struct Lane {
       for (int i = 0; i < FPL; i++)
         ch |= (int)clamp_foot(P.mu, lo(P, i), hi(P, i), C.sx[i], C.sy[i], C.sz[i], fc[3 * i], fc[3 * i + 1], fc[3 * i + 2], Cc.sx[i], Cc.sy[i],
                               Cc.sz[i]);
-      changed = group_or<G>(ch) != 0;
+      changed = group_or<G, S>(ch) != 0;
     }
     // (b) otherwise: ratio test over the faces outside the working set (tree min, face code in the low bits)
     bool blocked = false;
@@ -147,7 +148,7 @@ struct Lane {
       for (int w = 6 * FPL; w > 1; w = (w + 1) / 2)
 #pragma unroll
         for (int k = 0; k < w / 2; k++) cand[k] = min_nn(cand[k], cand[k + (w + 1) / 2]);
-      const double amin = group_min<G>(cand[0]);
+      const double amin = group_min<G, S>(cand[0]);
       blocked = !fresh && (amin < 1.0e299);
       bcode = blocked ? tag_code(amin) : -1;
       // f <- f^ + (1 - alpha)(f - f^): exactly f^ for a full step
@@ -218,7 +219,7 @@ struct Lane {
       for (int k = 0; k < 3; k++) sout[(OUT_F + 3 * (foot0 + i) + k) * SP + slot] = f[3 * i + k];
       word |= encode_foot(C.sx[i], C.sy[i], C.sz[i]) << (6 * (foot0 + i));
     }
-    word = (uint32_t)group_or<G>((int)word) | 0x80000000u;
+    word = (uint32_t)group_or<G, S>((int)word) | 0x80000000u;
     if (foot0 == 0) {
       sout[OUT_STAT * SP + slot] = __longlong_as_double((long long)(((unsigned long long)(uint32_t)iters << 32) | (uint32_t)status));
       sout[OUT_WORD * SP + slot] = __longlong_as_double((long long)(((unsigned long long)stance << 32) | word));
@@ -243,7 +244,7 @@ struct Lane {
 // swing edge, or any swinging leg on the very first call); if there is one, FootTrajectoryManager::
 // referenceStates(gait_map, bounds) (trajectory.cpp:308-344) CLEARS every stored trajectory and creates
 // those of the planned legs from p_start = Rwb foot + x (commander_node.cpp:456) and the planned foothold.
-template <int FPL>
+template <int FPL, bool STR = false>
 QC_DEV void swing_plan(CParams& P, const BatchIn& in, long robot, int foot0, uint32_t stance) {
   constexpr int GG = 4 / FPL;
   SwingState* S = in.swing_state + robot;
@@ -257,7 +258,7 @@ QC_DEV void swing_plan(CParams& P, const BatchIn& in, long robot, int foot0, uin
     const bool swing_now = !((stance >> (foot0 + i)) & 1u);
     if (swing_now && (first || prev[i] == 1)) plan |= 1 << i;
   }
-  const bool any = group_or<GG>(plan) != 0;
+  const bool any = group_or<GG, STR>(plan) != 0;
   double R[9], x[3], xdot[3], w[3], xdot_d[3];
   load9(in.Rwb, robot, R);
   load3(in.x, robot, x);
@@ -285,7 +286,7 @@ QC_DEV void swing_plan(CParams& P, const BatchIn& in, long robot, int foot0, uin
 // FPL = 4: one lane assembles a whole robot (dense restock of a big batch);
 // FPL = 4/G: the G lanes of a group share a robot, each doing its own feet
 // (small fills, where latency matters more than lane efficiency).
-template <bool KIN, int FPL>
+template <bool KIN, int FPL, bool STR = false>
 QC_DEV void assemble_to_stock(CParams& P, const BatchIn& in, const uint32_t* __restrict__ warm, long robot, int slot, int member,
                               double* __restrict__ sin) {
   constexpr int GG = 4 / FPL;
@@ -308,10 +309,10 @@ QC_DEV void assemble_to_stock(CParams& P, const BatchIn& in, const uint32_t* __r
       stance |= (ge0 && le) ? (1u << i) : 0u;
     }
   }
-  if (KIN && in.swing_state) swing_plan<FPL>(P, in, robot, foot0, stance);
+  if (KIN && in.swing_state) swing_plan<FPL, STR>(P, in, robot, foot0, stance);
   const uint32_t wv = warm ? warm[robot] : 0u;
   // non-finite inputs poison b, r or R: report QC_NOT_PD instead of iterating on NaNs
-  const bool bad = group_or<GG>(!(fin == 0.0) ? 1 : 0) != 0;
+  const bool bad = group_or<GG, STR>(!(fin == 0.0) ? 1 : 0) != 0;
   if (bad) stance |= 0x100u;
 #pragma unroll
   for (int i = 0; i < FPL; i++)
@@ -408,15 +409,16 @@ QC_DEV void store_from_stock(CParams& P, const BatchIn& in, const BatchOut& out,
 }
 
 // dense assembly of the next (up to 64) robots of the chunk into the input stock; returns how many
-template <int G, bool KIN>
+template <int G, bool KIN, bool STR = false>
 QC_DEV int restock(const DevParams* __restrict__ Pg, const BatchIn& in, const uint32_t* __restrict__ warm, long cursor, long end, int lane,
                    int member, double* __restrict__ sin) {
   const long left = end - cursor;
   const int k = left < 64 ? (int)left : 64;
   if (G > 1 && k <= 64 / G) {  // few robots: the lanes of a group share one
-    if (lane / G < k) {
+    const int grp = lane_group<G, STR>(lane);
+    if (grp < k) {
       CParams& P = *QC_PARAMS_HERE(Pg);
-      assemble_to_stock<KIN, 4 / G>(P, in, warm, cursor + lane / G, lane / G, member, sin);
+      assemble_to_stock<KIN, 4 / G, STR>(P, in, warm, cursor + grp, grp, member, sin);
     }
   } else if (lane < k) {
     CParams& P = *QC_PARAMS_HERE(Pg);
@@ -427,12 +429,13 @@ QC_DEV int restock(const DevParams* __restrict__ Pg, const BatchIn& in, const ui
 }
 
 // store the robots parked in the output stock: one per lane, or one per lane group when there are few
-template <int G, bool KIN>
+template <int G, bool KIN, bool STR = false>
 QC_DEV void flush_out(const DevParams* __restrict__ Pg, const BatchIn& in, const BatchOut& out, const double* __restrict__ sout, int out_n, int lane) {
   if (G > 1 && out_n <= 64 / G) {
-    if (lane / G < out_n) {
+    const int grp = lane_group<G, STR>(lane);
+    if (grp < out_n) {
       CParams& P = *QC_PARAMS_HERE(Pg);
-      store_from_stock<KIN, 4 / G>(P, in, out, sout, lane / G, lane & (G - 1));
+      store_from_stock<KIN, 4 / G>(P, in, out, sout, grp, lane_member<G, STR>(lane));
     }
   } else if (lane < out_n) {
     CParams& P = *QC_PARAMS_HERE(Pg);
@@ -447,8 +450,9 @@ QC_DEV void flush_out(const DevParams* __restrict__ Pg, const BatchIn& in, const
 template <bool KIN, bool UNIFORM, class Lane2>
 QC_DEV void finish_on_four_lanes(const DevParams* __restrict__ Pg, const Lane2& L, bool busy, unsigned long long bm, int slot, int member, int lane,
                                  double* __restrict__ sin, double* __restrict__ sout) {
-  using Eqp4 = EqpDiagW<UNIFORM, 4>;
+  using Eqp4 = EqpDiagW<UNIFORM, 4, !QC_NO_STRIDED>;
   using Lane4 = Lane<Eqp4, KIN>;
+  constexpr bool STR4 = Eqp4::kStrided;
   const int nb = __builtin_popcountll(bm) / 2;  // running robots
   if (nb == 0) return;
   constexpr int RS = 37;  // record stride in doubles (odd: the four lanes of a group read different banks)
@@ -476,11 +480,11 @@ QC_DEV void finish_on_four_lanes(const DevParams* __restrict__ Pg, const Lane2& 
   __syncthreads();
   Lane4 L4;
   Eqp4 eqp4(nullptr);
-  const int g4 = lane >> 2, j4 = lane & 3;
+  const int g4 = lane_group<4, STR4>(lane), j4 = lane_member<4, STR4>(lane);
   bool busy4 = g4 < nb;
   int slot4 = 0;
-  if (busy4) {
-    const double* rec = sin + g4 * RS;
+  {  // groups beyond the running robots shadow record 0: the strided layout keeps every lane in the loop (MFMA)
+    const double* rec = sin + (busy4 || !STR4 ? g4 : 0) * RS;
 #pragma unroll
     for (int k = 0; k < 6; k++) L4.Wr.b[k] = rec[k];
 #pragma unroll
@@ -500,7 +504,15 @@ QC_DEV void finish_on_four_lanes(const DevParams* __restrict__ Pg, const Lane2& 
     L4.have_f = true;
     eqp4.setup(*QC_PARAMS_HERE(Pg), L4.Wr, j4);
   }
-  while (busy4) busy4 = !L4.template iterate<Lane4::STEADY>(*QC_PARAMS_HERE(Pg), eqp4);
+  if constexpr (STR4) {
+    while (__builtin_amdgcn_ballot_w64(busy4) != 0) {
+      Lane4 T = L4;
+      const bool done = T.template iterate<Lane4::STEADY>(*QC_PARAMS_HERE(Pg), eqp4);
+      if (busy4) { L4 = T; busy4 = !done; }
+    }
+  } else {
+    while (busy4) busy4 = !L4.template iterate<Lane4::STEADY>(*QC_PARAMS_HERE(Pg), eqp4);
+  }
   if (g4 < nb) L4.push_result(sout, slot4);
 }
 
@@ -517,7 +529,9 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
   long cursor = (long)blockIdx.x * chunk;  // wave-uniform: next robot of this wave's chunk to assemble
   const long end = cursor + chunk < n ? cursor + chunk : n;
   const int lane = threadIdx.x;
-  const int member = lane & (G - 1);
+  constexpr bool STR = Eqp::kStrided;  // lane layout of a group (one-fill modes only)
+  static_assert(!STR || MODE != 0, "the refill bookkeeping of the persistent mode assumes adjacent lanes");
+  const int member = lane_member<G, STR>(lane);
   int stock_n = 0, stock_next = 0;  // input stock: slots [stock_next, stock_n) hold assembled robots
   int out_n = 0;                    // output stock: slots [0, out_n) hold finished results
   Lane<Eqp, KIN> L;
@@ -534,15 +548,50 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
     if (cursor >= end) return;
     UConst uc;  // RESIDENT: the recalculation's constants live in VGPRs (no scalar load + wait per recalculation)
     if constexpr (RESIDENT) uc = load_uconst(*QC_PARAMS_HERE(Pg));
-    stock_n = restock<G, KIN>(Pg, in, warm, cursor, end, lane, member, sin);
-    const int grp = lane / G;
+    stock_n = restock<G, KIN, STR>(Pg, in, warm, cursor, end, lane, member, sin);
+    const int grp = lane_group<G, STR>(lane);
     busy = grp < stock_n;
+    using LaneT = Lane<Eqp, KIN>;
+    if constexpr (STR) {
+      // Strided layout: the group sums run on the matrix pipe, and an MFMA reads its operands from ALL 64 lanes
+      // whatever EXEC says - the all-ones A operand included, which the compiler materialises under the current
+      // EXEC.  So nothing here may run under a partial EXEC: every lane carries a robot (groups beyond the fill
+      // shadow robot 0) through a wave-uniform loop, and only the lanes of running robots commit what a
+      // recalculation produced.
+      L.load_from_stock(sin, busy ? grp : 0, member);
+      eqp.setup(*QC_PARAMS_HERE(Pg), L.Wr, L.foot0);
+      {
+        LaneT T = L;
+        bool done;
+        if constexpr (RESIDENT) {
+          pin_uconst(uc);
+          done = T.template iterate<LaneT::FIRST>(uc, eqp);
+        } else {
+          done = T.template iterate<LaneT::FIRST>(*QC_PARAMS_HERE(Pg), eqp);
+        }
+        if (busy) { L = T; busy = !done; }
+      }
+      while (__builtin_amdgcn_ballot_w64(busy) != 0) {
+        LaneT T = L;
+        bool done;
+        if constexpr (RESIDENT) {
+          pin_uconst(uc);
+          done = T.template iterate<LaneT::STEADY>(uc, eqp);
+        } else {
+          done = T.template iterate<LaneT::STEADY>(*QC_PARAMS_HERE(Pg), eqp);
+        }
+        if (busy) { L = T; busy = !done; }
+      }
+      if (grp < stock_n) L.push_result(sout, grp);
+      __syncthreads();
+      flush_out<Eqp::G, KIN, STR>(Pg, in, out, sout, stock_n, lane);
+      return;
+    }
     if (busy) {
       L.load_from_stock(sin, grp, member);
       eqp.setup(*QC_PARAMS_HERE(Pg), L.Wr, L.foot0);
     }
     QC_CLK(0, 2);
-    using LaneT = Lane<Eqp, KIN>;
     if (busy) {  // every robot of a one-fill wave is fresh exactly once: the clamp step is peeled
       if constexpr (RESIDENT) {
         pin_uconst(uc);
@@ -572,7 +621,7 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
     }
     QC_CLK(7, 8);
     __syncthreads();
-    flush_out<Eqp::G, KIN>(Pg, in, out, sout, stock_n, lane);
+    flush_out<Eqp::G, KIN, STR>(Pg, in, out, sout, stock_n, lane);
     QC_CLK_END(8);
     return;
   }
@@ -984,13 +1033,13 @@ int qc_control_batch(qc_handle* h, size_t n, const qc_batch_in* in, const uint32
   } while (0)
   constexpr size_t kStock = qc::STOCK_DOUBLES * sizeof(double);
   if (!h->diag_w) QC_LAUNCH(qc::EqpDense, 1, kStock + 78 * 64 * sizeof(double));
-  else if (!h->uniform && G == 4 && single) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<false, 4>), 2, kStock, 1);
+  else if (!h->uniform && G == 4 && single) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<false, 4, !QC_NO_STRIDED>), 2, kStock, 1);
   else if (!h->uniform && G == 4) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<false, 4>), 2, kStock);
   else if (!h->uniform && G == 2 && single) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<false, 2>), 2, kStock, 1);
   else if (!h->uniform && G == 2) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<false, 2>), 2, kStock);
   else if (!h->uniform) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<false, 1>), 2, kStock);
-  else if (G == 4 && single && (long)blocks * 2 <= slots) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<true, 4>), 1, kStock, 2);  // one wave per SIMD
-  else if (G == 4 && single) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<true, 4>), 2, kStock, 1);
+  else if (G == 4 && single && (long)blocks * 2 <= slots) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<true, 4, !QC_NO_STRIDED>), 2, kStock, 2);  // one wave per SIMD is enough; the 256-register bound keeps the MFMA results out of AGPRs
+  else if (G == 4 && single) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<true, 4, !QC_NO_STRIDED>), 2, kStock, 1);
   else if (G == 4) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<true, 4>), 2, kStock);
   else if (G == 2 && single) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<true, 2>), 2, kStock, 1);
   else if (G == 2) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<true, 2>), 2, kStock);

@@ -29,6 +29,10 @@
 #define QC_CLK_PIN(arr)  // harness: pins the values of `arr` at this point so the scheduler cannot move a phase across its marker
 #endif
 
+#ifndef QC_NO_STRIDED
+#define QC_NO_STRIDED 0  // development: 1 keeps the adjacent-lane (DPP) layout in the 4-lanes-per-robot kernels
+#endif
+
 namespace qc {
 
 // Uniform (per-handle) constants, uploaded once by qc_create.
@@ -162,30 +166,102 @@ QC_DEV double max_abs_nn(double a, double b) {  // max(|a|, |b|)
 // All-reduce over the G lanes of a group.  x op y is commutative, so every
 // lane of the group ends up with the bit-identical result: decisions taken
 // from reduced values are uniform inside the group.
-template <int G>
+// Two lane layouts: adjacent lanes (member = lane & (G-1), DPP quad permutes), and - S = true, G = 4 only - the
+// four lanes {i, i+16, i+32, i+48} (member = lane >> 4, group = lane & 15).  In the strided layout the matrix pipe
+// does the sums: v_mfma_f64_4x4x4f64 with A = 1 computes, for every lane, the sum of B over the lanes that share
+// its (lane & 15) - one instruction per reduced double instead of four DPP moves and two adds (27 doubles per
+// recalculation: 412 vs 904 cycles, tools/ubench_mfma_reduce.hip), all four lanes getting the bit-identical dot
+// product.  min / max / or cross the 16-lane rows with the gfx950 row swaps (v_permlane16_swap, v_permlane32_swap:
+// with both operands equal they return the even and the odd row (half) broadcast, so op(r0, r1) is the reduction).
+QC_DEV double swap16_op_min(double v) {
+  const long long b = __double_as_longlong(v);
+  const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)b, (unsigned)b, false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
+  return min_nn(__longlong_as_double((long long)(((unsigned long long)hi[0] << 32) | lo[0])),
+                __longlong_as_double((long long)(((unsigned long long)hi[1] << 32) | lo[1])));
+}
+QC_DEV double swap32_op_min(double v) {
+  const long long b = __double_as_longlong(v);
+  const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)b, (unsigned)b, false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
+  return min_nn(__longlong_as_double((long long)(((unsigned long long)hi[0] << 32) | lo[0])),
+                __longlong_as_double((long long)(((unsigned long long)hi[1] << 32) | lo[1])));
+}
+QC_DEV double swap16_op_max(double v) {
+  const long long b = __double_as_longlong(v);
+  const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)b, (unsigned)b, false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
+  return max_nn(__longlong_as_double((long long)(((unsigned long long)hi[0] << 32) | lo[0])),
+                __longlong_as_double((long long)(((unsigned long long)hi[1] << 32) | lo[1])));
+}
+QC_DEV double swap32_op_max(double v) {
+  const long long b = __double_as_longlong(v);
+  const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)b, (unsigned)b, false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
+  return max_nn(__longlong_as_double((long long)(((unsigned long long)hi[0] << 32) | lo[0])),
+                __longlong_as_double((long long)(((unsigned long long)hi[1] << 32) | lo[1])));
+}
+template <int G, bool S = false>
 QC_DEV double group_sum(double v) {
-  if (G >= 2) v += dpp_xor1(v);
-  if (G >= 4) v += dpp_xor2(v);
-  return v;
+  static_assert(!S || G == 4, "the strided layout is a 4-lane layout");
+  if constexpr (S) {
+#ifdef QC_SUM_BY_SWAPS
+    {
+      const long long b = __double_as_longlong(v);
+      const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)b, (unsigned)b, false, false);
+      const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
+      v = __longlong_as_double((long long)(((unsigned long long)hi[0] << 32) | lo[0])) + __longlong_as_double((long long)(((unsigned long long)hi[1] << 32) | lo[1]));
+      const long long c = __double_as_longlong(v);
+      const auto lo2 = __builtin_amdgcn_permlane32_swap((unsigned)c, (unsigned)c, false, false);
+      const auto hi2 = __builtin_amdgcn_permlane32_swap((unsigned)(c >> 32), (unsigned)(c >> 32), false, false);
+      return __longlong_as_double((long long)(((unsigned long long)hi2[0] << 32) | lo2[0])) + __longlong_as_double((long long)(((unsigned long long)hi2[1] << 32) | lo2[1]));
+    }
+#endif
+    return __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, v, 0.0, 0, 0, 0);
+  } else {
+    if (G >= 2) v += dpp_xor1(v);
+    if (G >= 4) v += dpp_xor2(v);
+    return v;
+  }
 }
-template <int G>
+template <int G, bool S = false>
 QC_DEV double group_min(double v) {
-  if (G >= 2) v = min_nn(v, dpp_xor1(v));
-  if (G >= 4) v = min_nn(v, dpp_xor2(v));
-  return v;
+  if constexpr (S) {
+    return swap32_op_min(swap16_op_min(v));
+  } else {
+    if (G >= 2) v = min_nn(v, dpp_xor1(v));
+    if (G >= 4) v = min_nn(v, dpp_xor2(v));
+    return v;
+  }
 }
-template <int G>
+template <int G, bool S = false>
 QC_DEV double group_max(double v) {
-  if (G >= 2) v = max_nn(v, dpp_xor1(v));
-  if (G >= 4) v = max_nn(v, dpp_xor2(v));
-  return v;
+  if constexpr (S) {
+    return swap32_op_max(swap16_op_max(v));
+  } else {
+    if (G >= 2) v = max_nn(v, dpp_xor1(v));
+    if (G >= 4) v = max_nn(v, dpp_xor2(v));
+    return v;
+  }
 }
-template <int G>
+template <int G, bool S = false>
 QC_DEV int group_or(int v) {
-  if (G >= 2) v |= dpp_xor1_i(v);
-  if (G >= 4) v |= dpp_xor2_i(v);
-  return v;
+  if constexpr (S) {
+    const auto a = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+    const unsigned w = a[0] | a[1];
+    const auto c = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    return (int)(c[0] | c[1]);
+  } else {
+    if (G >= 2) v |= dpp_xor1_i(v);
+    if (G >= 4) v |= dpp_xor2_i(v);
+    return v;
+  }
 }
+// position of a lane in its layout
+template <int G, bool S>
+QC_DEV int lane_member(int lane) { return S ? lane >> 4 : lane & (G - 1); }
+template <int G, bool S>
+QC_DEV int lane_group(int lane) { return S ? lane & 15 : lane / G; }
 
 // ---------------------------------------------------------------- small math
 QC_DEV double rsqrt_nr(double d) {
@@ -608,7 +684,7 @@ QC_DEV FootCoef foot_coef(const PT& P, const FootW& fw, int sx, int sy, int sz, 
 
 // `stance` = 4-bit mask of the robot, `foot0` = first foot of this lane.
 // `lane_w`: the lane's foot weights (general form with lane groups; ignored otherwise).
-template <bool UNIFORM, int G, class PT>
+template <bool UNIFORM, int G, bool S, class PT>
 QC_DEV bool eqp_diagw(const PT& P, const FootW (&lane_w)[4 / G], const Wrench<4 / G>& Wr, const Cube<4 / G>& C, uint32_t stance, int foot0,
                       double (&f)[12 / G], double (&g)[12 / G]) {
   constexpr int FPL = 4 / G;
@@ -682,12 +758,12 @@ QC_DEV bool eqp_diagw(const PT& P, const FootW (&lane_w)[4 / G], const Wrench<4 
   for (int r = 0; r < 6; r++) {
 #pragma unroll
     for (int c = 0; c <= r; c++) {
-      double s = group_sum<G>(M[MI(r, c)]);
+      double s = group_sum<G, S>(M[MI(r, c)]);
       if constexpr (!UNIFORM) s += P.V[6 * r + c];
       else if (r == c) s += P.Vd[r];  // S^-1 is diagonal here: nothing to add off the diagonal
       M[MI(r, c)] = s;
     }
-    rhs[r] = group_sum<G>(rhs[r]) - Wr.b[r];
+    rhs[r] = group_sum<G, S>(rhs[r]) - Wr.b[r];
   }
   QC_CLK_PIN(M); QC_CLK_PIN(rhs);
   QC_CLK(3, 4);
@@ -759,9 +835,10 @@ QC_DEV bool eqp_diagw(const PT& P, const FootW (&lane_w)[4 / G], const Wrench<4 
   return ok;
 }
 
-template <bool UNIFORM, int GROUP>
+template <bool UNIFORM, int GROUP, bool STRIDED = false>
 struct EqpDiagW {
   static constexpr int G = GROUP;
+  static constexpr bool kStrided = STRIDED;  // lane layout of the group, see group_sum
   static constexpr bool kUniform = UNIFORM;
   static constexpr bool kRepackTail = GROUP == 2;  // one-fill waves finish their stragglers 4 lanes per robot
   FootW lane_w[4 / GROUP];  // general form with lane groups: the weights of this lane's feet (dead otherwise)
@@ -776,7 +853,7 @@ struct EqpDiagW {
   template <class PT>
   QC_DEV bool solve(const PT& P, const Wrench<4 / GROUP>& Wr, const Cube<4 / GROUP>& C, uint32_t stance, int foot0, double (&f)[12 / GROUP],
                     double (&g)[12 / GROUP]) {
-    return eqp_diagw<UNIFORM, GROUP>(P, lane_w, Wr, C, stance, foot0, f, g);
+    return eqp_diagw<UNIFORM, GROUP, STRIDED>(P, lane_w, Wr, C, stance, foot0, f, g);
   }
 };
 
@@ -795,6 +872,7 @@ struct EqpDiagW {
 
 struct EqpDense {
   static constexpr int G = 1;
+  static constexpr bool kStrided = false;
   static constexpr bool kRepackTail = false;
   double* Qs;    // LDS base of this lane: element k at Qs[k * 64]
   double c[12];  // c = -2 A^T S b (BC.cpp:153)

