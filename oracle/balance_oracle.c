@@ -330,10 +330,15 @@ int oracle_qp_solve(const double* H, const double* g, const double* C, const dou
     if (worst < 0) {
       /* a checker must not certify an infeasible point: nearly parallel rows (mu -> 0) can defeat the
        * dependent-row logic above; report failure instead of a wrong ORACLE_OK */
+      double fs = 1.0; /* scale of the solution: the KKT solves leave ~cond*eps*|f| on the pinned rows */
+      for (int k = 0; k < NV; k++) if (fabs(f[k]) > fs) fs = fabs(f[k]);
       for (int r = 0; r < NC; r++) {
         double cf = 0.0;
         for (int k = 0; k < NV; k++) cf += C[r * NV + k] * f[k];
-        if (cf > ub[r] + 1e-7 * (1 + fabs(ub[r])) || cf < lb[r] - 1e-7 * (1 + fabs(lb[r]))) return ORACLE_MAX_ITER;
+        if (cf > ub[r] + 1e-7 * (fs + fabs(ub[r])) || cf < lb[r] - 1e-7 * (fs + fabs(lb[r]))) {
+          if (iters_out) *iters_out = it + 1;
+          return ORACLE_MAX_ITER;
+        }
       }
       if (lam_out) memcpy(lam_out, lam, sizeof(lam));
       if (iters_out) *iters_out = it + 1;
