@@ -1032,7 +1032,8 @@ int qc_control_batch(qc_handle* h, size_t n, const qc_batch_in* in, const uint32
     else qc::balance_kernel<EQP, false, MINW, ##__VA_ARGS__><<<dim3(blocks), dim3(64), LDS, st>>>(h->d_params, (long)n, bi, warm, bo, chunk, refill_t);     \
   } while (0)
   constexpr size_t kStock = qc::STOCK_DOUBLES * sizeof(double);
-  if (!h->diag_w) QC_LAUNCH(qc::EqpDense, 1, kStock + 78 * 64 * sizeof(double));
+  if (!h->diag_w && single) QC_LAUNCH(qc::EqpDense, 1, kStock + 78 * 64 * sizeof(double), 1);
+  else if (!h->diag_w) QC_LAUNCH(qc::EqpDense, 1, kStock + 78 * 64 * sizeof(double));
   else if (!h->uniform && G == 4 && single) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<false, 4, !QC_NO_STRIDED>), 2, kStock, 1);
   else if (!h->uniform && G == 4) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<false, 4>), 2, kStock);
   else if (!h->uniform && G == 2 && single) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<false, 2>), 2, kStock, 1);
