@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define QC_ABI_VERSION 2
+#define QC_ABI_VERSION 3
 
 /* Replaces the constructor arguments of BalanceController
  * (balance_controller.hpp:85-88; defaults in commander_node.cpp:289-334 and
@@ -92,6 +92,12 @@ typedef struct qc_batch_in {
    * heuristic), FootTrajectoryManager::referenceStates / referenceState and the sextic FootTrajectory
    * (trajectory.cpp:220-277, 308-388), then fed to the swing-leg torque chain above. */
   struct qc_swing_state* swing_state;
+  /* ABI v3, optional: the gait clock.  Time step [n] (seconds) since the robot's previous tick.  When given,
+   * `gait_phase` is IN/OUT: at the start of the robot's tick its four phases advance the way
+   * GaitScheduler::update does (gait.cpp:113-123): phase += 1 / (t_swing + t_stance) * dt, wrapped by
+   * fmod(., 1), with the periods installed by qc_set_gait - and the contact rule, the foothold planner and
+   * the swing trajectories of this tick see the advanced phases.  The buffer behind `gait_phase` is written. */
+  const double* gait_dt;
 } qc_batch_in;
 
 /* FootPlanner::state_map_ (foot_planner.hpp) + FootTrajectoryManager::traj_map_ (trajectory.hpp), per robot. */

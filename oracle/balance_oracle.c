@@ -713,3 +713,11 @@ void oracle_tick_planned_batch(const oracle_params* P, const oracle_kinematics* 
                             joint_tau + 12 * i, status ? status + i : 0, 1);
   }
 }
+
+/* gait.cpp:113-123 */
+void oracle_gait_update(const oracle_kinematics* K, long n, double* phases, const double* dt) {
+  for (long i = 0; i < n; i++) {
+    const double step = 1.0 / (K->t_swing + K->t_stance) * dt[i];
+    for (int l = 0; l < 4; l++) phases[4 * i + l] = fmod(phases[4 * i + l] + step, 1.0);
+  }
+}

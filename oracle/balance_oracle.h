@@ -120,6 +120,8 @@ typedef struct oracle_swing_state {
 void oracle_swing_references(const oracle_kinematics* K, oracle_swing_state* st, const double* Rwb, const double* x,
                              const double* xdot, const double* w, const double* xdot_d, const double* feet_body,
                              const unsigned char* stance, const double* phase, double* pos, double* vel);
+/* GaitScheduler::update(dt), gait.cpp:113-123: phases[n][4] += 1 / (t_swing + t_stance) * dt[n], wrapped by fmod(., 1). */
+void oracle_gait_update(const oracle_kinematics* K, long n, double* phases, const double* dt);
 /* Full tick with on-the-fly swing references: stance from the gait rule, FK, planner/trajectories,
  * control(), J^T torques for stance legs, IK/J^-1/PD torques for swing legs. */
 void oracle_tick_planned_batch(const oracle_params* P, const oracle_kinematics* K, long n, oracle_swing_state* states,

@@ -188,3 +188,12 @@ def tick_planned_batch(P, batch, states, kin=None, threads=1, max_iter=200):
     lib().oracle_tick_planned_batch(C.byref(p), C.byref(kin), C.c_long(n), states.ctypes.data_as(C.c_void_p), *[_dp(v) for v in a],
                                     _dp(grf), _dp(tau), status.ctypes.data_as(C.POINTER(C.c_int)), C.c_int(threads))
     return dict(grf_body=grf, joint_tau=tau, status=status)
+
+
+def gait_update(phases, dt, kin=None):
+    """GaitScheduler::update(dt) on [n, 4] phases, in place (gait.cpp:113-123)."""
+    kin = kin or default_kinematics()
+    assert phases.dtype == np.float64 and phases.flags["C_CONTIGUOUS"]
+    dt = np.ascontiguousarray(dt, np.float64)
+    lib().oracle_gait_update(C.byref(kin), C.c_long(phases.shape[0]), _dp(phases), _dp(dt))
+    return phases

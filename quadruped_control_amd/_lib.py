@@ -27,7 +27,7 @@ class QcParams(C.Structure):
 class QcBatchIn(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in
                 ("Rwb", "Rwb_d", "x", "xdot", "w", "x_d", "xdot_d", "w_d", "feet", "stance", "joint_q", "gait_phase", "gait_duty",
-                 "swing_pos", "swing_vel", "joint_qdot", "swing_state")]
+                 "swing_pos", "swing_vel", "joint_qdot", "swing_state", "gait_dt")]
 
 
 class QcBatchOut(C.Structure):

@@ -176,6 +176,7 @@ class BalanceController:
                 raise ValueError("stance: need contiguous uint8 [n,4]")
             bi.stance = st.data_ptr()
         for name, k in (("gait_phase", 4), ("gait_duty", 1),  # on-device contact rule (gait.cpp:125-134)
+                        ("gait_dt", 1),  # on-device gait clock (gait.cpp:113-123): gait_phase is advanced in place
                         ("swing_pos", 12), ("swing_vel", 12), ("joint_qdot", 12)):  # swing-leg torques
             t = batch.get(name)
             if t is not None:
@@ -229,7 +230,7 @@ class BalanceController:
         for name, _ in _IN_FIELDS + (("joint_q", 12),):
             if batch.get(name) is not None:
                 setattr(bi, name, batch[name].data_ptr())
-        for name in ("stance", "gait_phase", "gait_duty", "swing_pos", "swing_vel", "joint_qdot", "swing_state"):
+        for name in ("stance", "gait_phase", "gait_duty", "gait_dt", "swing_pos", "swing_vel", "joint_qdot", "swing_state"):
             if batch.get(name) is not None:
                 setattr(bi, name, batch[name].data_ptr())
         bo = _lib.QcBatchOut()
@@ -275,9 +276,11 @@ class BalanceController:
             if ss.dtype != SWING_STATE_DTYPE or not ss.flags["C_CONTIGUOUS"] or ss.shape != (n,):
                 raise ValueError("swing_state: need a C-contiguous new_swing_states(n) array")
             bi.swing_state = ss.ctypes.data
-        for name in ("gait_phase", "gait_duty", "swing_pos", "swing_vel", "joint_qdot"):
+        for name in ("gait_phase", "gait_duty", "gait_dt", "swing_pos", "swing_vel", "joint_qdot"):
             if batch.get(name) is not None:
                 a = np.ascontiguousarray(batch[name], dtype=np.float64)
+                if name == "gait_phase" and batch.get("gait_dt") is not None and a is not batch[name]:
+                    raise ValueError("gait_phase: with gait_dt the array is advanced in place, pass a C-contiguous float64 array")
                 keep.append(a)
                 setattr(bi, name, a.ctypes.data)
         out = {"grf_body": np.zeros((n, 12)), "status": np.zeros(n, dtype=np.int32)}

@@ -301,9 +301,23 @@ QC_DEV void assemble_to_stock(CParams& P, const BatchIn& in, const uint32_t* __r
     // GaitScheduler::phase(), gait.cpp:125-134 (almost_equal = |a-b| < 1e-12, math/numerics.cpp:18-21)
     const double duty = in.gait_duty ? in.gait_duty[robot] : P.stance_phase;
     stance = 0;
+    double phs[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) phs[i] = in.gait_phase[4 * robot + i];
+    if (in.gait_dt) {  // GaitScheduler::update(dt), gait.cpp:113-123: the clock of this robot advances first
+      const double step = 1.0 / (P.t_swing + P.t_stance) * in.gait_dt[robot];
+      double* wp = const_cast<double*>(in.gait_phase) + 4 * robot;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        phs[i] = fmod(phs[i] + step, 1.0);
+        // every lane of the group computes the same four values; the first one stores them (read again, past
+        // the vector L1, by this wave's store phase for the swing trajectories)
+        if (member == 0) __hip_atomic_store(wp + i, phs[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      const double ph = in.gait_phase[4 * robot + i];
+      const double ph = phs[i];
       const bool ge0 = (ph > 0.0) || (fabs(ph) < 1.0e-12);
       const bool le = (ph < duty) || (fabs(ph - duty) < 1.0e-12);
       stance |= (ge0 && le) ? (1u << i) : 0u;
@@ -370,7 +384,9 @@ QC_DEV void store_from_stock(CParams& P, const BatchIn& in, const BatchOut& out,
             p0[r] = __hip_atomic_load(&S->p_start[3 * (foot0 + i) + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             pf[r] = __hip_atomic_load(&S->p_final[3 * (foot0 + i) + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
-          track_swing(P, in.gait_phase[4 * idx + foot0 + i], p0, pf, sp, sv);
+          const double ph = in.gait_dt ? __hip_atomic_load(in.gait_phase + 4 * idx + foot0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                       : in.gait_phase[4 * idx + foot0 + i];
+          track_swing(P, ph, p0, pf, sp, sv);
           if (!has) sp[0] = sp[1] = sp[2] = sv[0] = sv[1] = sv[2] = 0.0;  // no trajectory: FootState() (:387)
         } else {
 #pragma unroll
@@ -987,11 +1003,12 @@ int qc_control_batch(qc_handle* h, size_t n, const qc_batch_in* in, const uint32
   const int n_sw = (in->swing_pos ? 1 : 0) + (in->swing_vel ? 1 : 0) + (in->joint_qdot ? 1 : 0);
   if (!in->swing_state && n_sw != 0 && (n_sw != 3 || !in->joint_q || !out->joint_tau))
     return fail(QC_ERR_INVALID, "qc_control_batch: swing_pos, swing_vel and joint_qdot go together and need joint_q and joint_tau");
+  if (in->gait_dt && (!in->gait_phase || in->stance)) return fail(QC_ERR_INVALID, "qc_control_batch: gait_dt advances gait_phase (needed, and stance must be NULL)");
   if (in->swing_state && (!in->joint_q || !in->joint_qdot || !in->gait_phase || !out->joint_tau || in->swing_pos || in->swing_vel))
     return fail(QC_ERR_INVALID, "qc_control_batch: swing_state needs joint_q, joint_qdot, gait_phase and joint_tau, and excludes swing_pos/swing_vel");
   qc::BatchIn bi{in->Rwb, in->Rwb_d, in->x, in->xdot, in->w, in->x_d, in->xdot_d, in->w_d, in->feet, in->stance, in->joint_q,
                  in->gait_phase, in->gait_duty, in->swing_pos, in->swing_vel, in->joint_qdot,
-                 reinterpret_cast<qc::SwingState*>(in->swing_state)};
+                 reinterpret_cast<qc::SwingState*>(in->swing_state), in->gait_dt};
   qc::BatchOut bo{out->grf_body, out->status, out->active_set, out->iterations, out->joint_tau};
   // One wave per 64-thread block; a group of G lanes per robot.  The group
   // width trades latency for throughput: G = 4 (foot per lane) cuts the serial
@@ -1066,7 +1083,7 @@ int qc_control_batch_host(qc_handle* h, size_t n, const qc_batch_in* in, const u
   if (!h->stream) QC_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   const bool pinned = n <= kPinnedMaxN;
   // layout (all 16-byte aligned slices): 48 doubles in, 12 doubles out, 4 x 4-byte words, optional arrays
-  const size_t per = 48 * 8 + 12 * 8 + 4 * 4 + 8 + 12 * 8 + 12 * 8 + 5 * 8 + 3 * 12 * 8 + sizeof(qc_swing_state);
+  const size_t per = 48 * 8 + 12 * 8 + 4 * 4 + 8 + 12 * 8 + 12 * 8 + 6 * 8 + 3 * 12 * 8 + sizeof(qc_swing_state);
   const size_t need = n * per + 512;
   char* base;
   if (pinned) {
@@ -1115,6 +1132,7 @@ int qc_control_batch_host(qc_handle* h, size_t n, const qc_batch_in* in, const u
   din.joint_q = (const double*)put(in->joint_q, n * 12 * 8);
   din.gait_phase = (const double*)put(in->gait_phase, n * 4 * 8);
   din.gait_duty = (const double*)put(in->gait_duty, n * 8);
+  din.gait_dt = (const double*)put(in->gait_dt, n * 8);
   din.swing_pos = (const double*)put(in->swing_pos, n * 12 * 8);
   din.swing_vel = (const double*)put(in->swing_vel, n * 12 * 8);
   din.joint_qdot = (const double*)put(in->joint_qdot, n * 12 * 8);
@@ -1137,6 +1155,7 @@ int qc_control_batch_host(qc_handle* h, size_t n, const qc_batch_in* in, const u
   get(out->iterations, dout.iterations, n * 4);
   get(out->joint_tau, dout.joint_tau, n * 12 * 8);
   get(in->swing_state, din.swing_state, n * sizeof(qc_swing_state));
+  if (in->gait_dt) get(const_cast<double*>(in->gait_phase), din.gait_phase, n * 4 * 8);  // the advanced clock
   QC_HIP(cerr);
   if (!pinned) QC_HIP(hipStreamSynchronize(h->stream));
   return QC_OK;
@@ -1146,7 +1165,7 @@ int qc_control(qc_handle* h, const double* Rwb, const double* Rwb_d, const doubl
                const double* w, const double* x_d, const double* xdot_d, const double* w_d, const double* feet,
                const uint8_t* stance, double* grf_body, int32_t* status) {
   if (!h || !status) return fail(QC_ERR_INVALID, "qc_control: null argument");
-  qc_batch_in in{Rwb, Rwb_d, x, xdot, w, x_d, xdot_d, w_d, feet, stance, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  qc_batch_in in{Rwb, Rwb_d, x, xdot, w, x_d, xdot_d, w_d, feet, stance, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   // The handle remembers the working set of its previous call and starts from it - the per-instance hot-start
   // memory of the reference's SQProblem (BC.hpp:161, BC.cpp:191-202).  Same minimiser either way (strictly convex).
   uint32_t word_in = h->last_word, word_out = 0;

@@ -122,6 +122,7 @@ struct BatchIn {
   const double* swing_vel;
   const double* joint_qdot;
   struct SwingState* swing_state;
+  const double* gait_dt;
 };
 struct BatchOut {
   double* grf_body;

@@ -646,3 +646,48 @@ def test_non_finite_states_in_the_stateful_tick(q):
         assert np.abs(o["joint_tau"] - r["joint_tau"])[fin].max() < 2e-5
         saw_nan |= bool(np.isnan(o["joint_tau"]).any())
     assert saw_nan
+
+
+def test_on_device_gait_clock(q):
+    """ABI v3: `gait_dt` advances the per-leg phases on the device the way GaitScheduler::update does
+    (gait.cpp:113-123) before the contact rule, the planner and the trajectories of the tick use them; the
+    phases carried by the device over many ticks stay bit-equal to the oracle's clock and the complete tick
+    tracks the oracle fed with those phases."""
+    from oracle import c_oracle as O
+    from quadruped_control_amd import workloads as W
+
+    P = q.cheetah_params(0.6)
+    n = 3000
+    rng = np.random.default_rng(8)
+    base = W.with_swing_references(W.with_joint_angles(W.config3(n)))
+    base = {k: v for k, v in base.items() if k not in ("stance", "swing_pos", "swing_vel")}
+    for t_sw, t_st in ((0.18, 0.8), (0.3, 0.3)):
+        kin = O.default_kinematics(); kin.t_swing = t_sw; kin.t_stance = t_st
+        ctl = q.BalanceController.from_params(P)
+        ctl.set_gait(t_sw, t_st)
+        dev_phase = np.ascontiguousarray(np.fmod(np.array([0.0, 0.5, 0.5, 0.0])[None] + rng.uniform(0, 1, (n, 1)), 1.0))
+        ref_phase = dev_phase.copy()
+        dev_state, ref_state = q.new_swing_states(n), O.new_swing_states(n)
+        for tick in range(40):
+            dt = rng.uniform(0.0, 0.02, n)
+            b = dict(base, gait_phase=dev_phase, gait_dt=dt, swing_state=dev_state)
+            o = ctl.control_batch_host(b, want_torques=True)
+            O.gait_update(ref_phase, dt, kin=kin)
+            assert np.array_equal(dev_phase, ref_phase), tick  # the device wrote the advanced clock back
+            r = O.tick_planned_batch(P, dict(base, gait_phase=ref_phase), ref_state, kin=kin, threads=8)
+            assert np.array_equal(o["status"], r["status"])
+            assert np.array_equal(dev_state["leg_state"], ref_state["leg_state"]) and np.array_equal(dev_state["has_traj"], ref_state["has_traj"])
+            assert np.max(np.abs(o["joint_tau"] - r["joint_tau"])) < 2e-5, tick
+        assert (ref_state["has_traj"] == 1).any()
+    # plain path: clock + contact rule only
+    ph = np.ascontiguousarray(rng.uniform(0, 1, (n, 4))); ph0 = ph.copy()
+    dt = rng.uniform(0.0, 0.5, n)
+    b2 = {k: v for k, v in W.config2(n).items() if k != "stance"}
+    out = ctl.control_batch_host(dict(b2, gait_phase=ph, gait_dt=dt))
+    want = O.gait_update(ph0, dt, kin=kin)
+    assert np.array_equal(ph, want)
+    from quadruped_control_amd import leg_state_from_phase
+    ref = ctl.control_batch_host(dict(b2, stance=leg_state_from_phase(want, 0.5)))
+    assert np.array_equal(out["grf_body"], ref["grf_body"])
+    with pytest.raises(RuntimeError, match="gait_dt"):
+        ctl.control_batch_host(dict(W.config2(8), gait_dt=np.zeros(8)))

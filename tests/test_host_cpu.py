@@ -20,14 +20,14 @@ def test_abi_exports_match_header(built):
     from quadruped_control_amd import _lib
 
     assert set(_lib.EXPORTS) == declared
-    assert _lib.load().qc_abi_version() == 2
+    assert _lib.load().qc_abi_version() == 3
 
 
 def test_param_struct_layout_matches_c():
     from quadruped_control_amd import _lib
 
     assert ctypes.sizeof(_lib.QcParams) == 8 * (4 + 9 + 36 + 144 + 6 + 3 * 4) + 8
-    assert ctypes.sizeof(_lib.QcBatchIn) == 17 * 8 and ctypes.sizeof(_lib.QcBatchOut) == 5 * 8
+    assert ctypes.sizeof(_lib.QcBatchIn) == 18 * 8 and ctypes.sizeof(_lib.QcBatchOut) == 5 * 8
     assert ctypes.sizeof(_lib.QcKinematics) == 49 * 8
     assert ctypes.sizeof(_lib.QcSwingState) == 224
 
