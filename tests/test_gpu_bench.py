@@ -42,9 +42,12 @@ def test_bench_line_single_gpu(built):
 def test_bench_two_ranks_torchrun(built):
     """The N > 1 launch the driver uses, on this box's single GPU (QC_BENCH_ONE_DEVICE: both ranks on cuda:0, gloo
     for the barrier / counter reduction instead of RCCL)."""
+    import socket
+
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
     env = dict(os.environ, QC_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "3", "--gather-results"]
+           "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "3", "--gather-results"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _last_json(r.stdout)
