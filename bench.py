@@ -1,27 +1,35 @@
 #!/usr/bin/env python
 """Headline benchmark: friction-cone QPs/sec of the batched balance controller.
 
-  python bench.py --gpus N --steps K --warmup W [--config 2|3|4|5] [--n ROBOTS]
+  python bench.py --gpus N --steps K --warmup W [--config 2|3|4|5] [--robots R] [--scaling strong|weak]
 
-A "step" is one pass of the hot path (one qc_control_batch launch) over one
-batch of synthetic robots that is already resident in HBM.  Default workload =
-BASELINE.json configs[1]: 4096 randomised COM poses/velocities, all four feet
-in contact, mu = 0.6 (SURVEY.md 8d "config 2").  With N > 1 (launched by
-torch.distributed.run, one rank per GPU) every rank owns its own shard of the
-batch axis (weak scaling: `n` robots per GPU); the path has no data exchange,
-RCCL is used only for the barrier and to reduce the timing / solved counters.
+A "step" is one pass of the hot path (one qc_control_batch launch) over one batch of synthetic robots that is
+resident in HBM.  N = 1 (default): BASELINE.json configs[1] - 4096 randomised COM poses/velocities, all four feet
+in contact, mu = 0.6 (SURVEY.md 8d "config 2").  N > 1: BASELINE.json configs[4] ("config 5") - a FIXED total of
+2,097,152 robots of the config-3 distribution, rank k of N owning the contiguous shard shard_bounds(2097152, k, N)
+("scaling": "strong"; `--scaling weak` keeps `--robots` robots per GPU instead).  The path has no data exchange: RCCL
+(torch.distributed backend "nccl") carries only the barrier and the reduction of the timing / solved counters.
 
-Prints ONE JSON line on rank 0 (see the task contract): value = robots solved
-per second over all ranks; roofline = algorithmic bytes (488 B per robot:
-388 B read + 100 B written) / average kernel time measured with
-HIP events on the launch stream; cpu_baseline = the C oracle (a port, not
-qpOASES) timed on the host cores on the same workload.
+`python bench.py --gpus N` started WITHOUT a launcher (no WORLD_SIZE in the environment) starts its own N ranks,
+one per GPU, through torch.distributed.run; started by a launcher it checks that --gpus equals WORLD_SIZE.
+
+Cold-cache protocol: the per-GPU working sets of configs 2-5 (2 ... 130 MB) fit the 256 MiB
+Infinity Cache, so the timed loop rotates through K distinct input/output sets with K x bytes > 512 MiB; `value`
+and `roofline` are measured that way (inputs come from HBM), and the replay of ONE resident set is reported next
+to it as `warm_cache`.
+
+Prints ONE JSON line on rank 0 (see the task contract): value = robots solved per second over all ranks;
+roofline = algorithmic bytes (488 B per robot: 388 B read + 100 B written) / average kernel time
+measured with HIP events on the launch stream; cpu_baseline = the C oracle (a port, not qpOASES) timed on the host
+cores on the same workload.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -32,37 +40,54 @@ if ROOT not in sys.path:
 BYTES_PER_ROBOT_COLD = 488   # 48 f64 + 4 B stance read; 12 f64 + 4 B status written
 BYTES_PER_ROBOT_WARM = 496   # + 4 B warm word read + 4 B active-set word written
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
+ROTATE_BYTES = 512 << 20     # the rotating sets of the cold-cache protocol cover more than this
+CONFIG5_TOTAL = 2097152
 
-CONFIG_N = {2: 4096, 3: 65536, 4: 262144, 5: 262144}  # robots per GPU
+CONFIG_N = {2: 4096, 3: 65536, 4: 262144, 5: 262144}  # robots per GPU (weak scaling / N = 1)
 CONFIG_DESC = {
     2: "config2: batch of {n} randomised COM poses/velocities per GPU, all 4 feet in contact, mu=0.6 pyramid cone, cold start",
     3: "config3: batch of {n} per GPU, mixed 2/3/4-foot contact states from trot/walk gait schedules, cold start",
     4: "config4: batch of {n} per GPU, tick 1 warm-started from tick 0's active set (dt=1/300 s)",
-    5: "config5: 2,097,152-robot batch (config-3 distribution) sharded contiguously, {n} per GPU",
+    5: "config5: 2,097,152-robot batch (config-3 distribution, seed 0x5EED0005) sharded contiguously, {n} robots on this GPU's shard",
 }
 
 
-def make_batch(cfg, n, start):
+def kernel_src_sha16():
+    """Fingerprint of the kernel sources this run was built from (the .git directory does not travel to the GPU
+    box): profiles carry it, so a committed PMC pass can be matched to the kernels that produced it."""
+    h = hashlib.sha256()
+    for f in ("quadruped_control_amd/csrc/qc_balance.hip", "quadruped_control_amd/csrc/qc_device.hpp", "include/qc_balance.h"):
+        h.update(open(os.path.join(ROOT, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def make_batch(cfg, n, start, seed_shift=0):
     from quadruped_control_amd import workloads as W
 
+    seed = W.SEEDS[cfg] + seed_shift
     if cfg == 2:
-        return W.config2(n, start=start), None
+        return W.config2(n, start=start, seed=seed), None
     if cfg == 3:
-        return W.config3(n, start=start), None
+        return W.config3(n, start=start, seed=seed), None
     if cfg == 4:
-        t0, t1 = W.config4(n, start=start)
+        t0, t1 = W.config4(n, start=start, seed=seed)
         return t1, t0
-    return W.config5(n, start=start), None
+    return W.config5(n, start=start, seed=seed), None
 
 
-def time_steps(ctl, dev_batch, warm, out, steps, warmup, dist=None):
-    """W untimed steps, then K timed steps bracketed by barrier + synchronize.
+def rotation_sets(n, warm):
+    per = (BYTES_PER_ROBOT_WARM if warm else BYTES_PER_ROBOT_COLD) * n
+    return 1 if per > ROTATE_BYTES else ROTATE_BYTES // per + 1
+
+
+def time_launches(launches, steps, warmup, dist=None):
+    """W untimed steps, then K timed steps bracketed by barrier + synchronize; step i runs launches[i % len].
     Returns (wall seconds for K steps, HIP-event seconds for K steps)."""
     import torch
 
-    launch, _ = ctl.plan_batch(dev_batch, warm=warm, out=out)  # arguments marshalled once; launch() = one C call
-    for _ in range(warmup):
-        launch()
+    m = len(launches)
+    for i in range(max(warmup, min(m, 8))):  # at least a few sets so that every code path is paged in
+        launches[i % m]()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -71,8 +96,8 @@ def time_steps(ctl, dev_batch, warm, out, steps, warmup, dist=None):
     ev1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()  # torch's current stream == the stream control_batch launches on
-    for _ in range(steps):
-        launch()
+    for i in range(steps):
+        launches[(warmup + i) % m]()
     ev1.record()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0  # this rank's K steps; the caller takes the MAX over ranks
@@ -82,39 +107,63 @@ def time_steps(ctl, dev_batch, warm, out, steps, warmup, dist=None):
     return wall, ev0.elapsed_time(ev1) * 1e-3
 
 
-def run_config(ctl, q, cfg, n, start, steps, warmup, dist=None, device=0, fused=False):
+def run_config(ctl, q, cfg, n, start, steps, warmup, dist=None, device=0, fused=False, protocols=("cold", "warm")):
+    """Runs the workload under the cold-cache protocol (rotating sets) and/or as a replay of one resident set.
+    Returns dict(cold=(wall, event_s), warm_cache=(wall, event_s), solved, n, sets, batch (host, set 0), warm)."""
+    import numpy as np
     import torch
 
+    dev = f"cuda:{device}"
     batch, prev = make_batch(cfg, n, start)
     if fused:  # SURVEY 8f rows 1+2: joint angles in (device FK), joint torques out (J^T f, clamped)
         from quadruped_control_amd import workloads as W
 
         batch = W.with_joint_angles(batch, start=start)
         if fused == "full":  # rows 3+4 too: contact state from gait phases, swing planner/trajectories/IK/PD
-            import numpy as np
-
             batch = W.with_swing_references(batch, start=start)
             idx = np.arange(start, start + n, dtype=np.uint64)
             phase = np.fmod(np.array([0.0, 0.5, 0.5, 0.0])[None] + W.uniform(0x5EED0009, idx, 3)[:, None], 1.0)
             batch = {k: v for k, v in batch.items() if k not in ("stance", "swing_pos", "swing_vel")}
             batch["gait_phase"] = np.ascontiguousarray(phase)
-    dev_batch = q.to_device(batch, device)
+    is_warm = prev is not None
+    sets = rotation_sets(n, is_warm) if ("cold" in protocols and not fused) else 1
+    # set 0 is the canonical workload; sets 1.. hold other robots of the same distribution (shifted seed)
+    hosts, prevs = [batch], [prev]
+    for j in range(1, sets):
+        b, p = make_batch(cfg, n, start, seed_shift=0x100 * j)
+        hosts.append(b)
+        prevs.append(p)
+    big = {k: torch.from_numpy(np.concatenate([h[k] for h in hosts])).to(dev) for k in batch}
+    del hosts
     if fused == "full":
-        dev_batch["swing_state"] = torch.from_numpy(q.new_swing_states(n).view("uint8").reshape(-1).copy()).to(f"cuda:{device}")
+        big["swing_state"] = torch.from_numpy(q.new_swing_states(n).view("uint8").reshape(-1).copy()).to(dev)
+    out = {"grf_body": torch.empty((sets * n, 12), dtype=torch.float64, device=dev),
+           "status": torch.empty((sets * n,), dtype=torch.int32, device=dev)}
     warm = None
-    if prev is not None:  # config 4: tick 0 (cold) produces the warm-start words for tick 1
-        o0 = ctl.control_batch(q.to_device(prev, device), want_active_set=True)
+    if is_warm:  # config 4: tick 0 (cold) produces the warm-start words for tick 1
+        big_prev = {k: torch.from_numpy(np.concatenate([p[k] for p in prevs])).to(dev) for k in prevs[0]}
+        o0 = ctl.control_batch(big_prev, want_active_set=True)
         torch.cuda.synchronize()
         warm = o0["active_set"]
-    out = {"grf_body": torch.empty((n, 12), dtype=torch.float64, device=f"cuda:{device}"),
-           "status": torch.empty((n,), dtype=torch.int32, device=f"cuda:{device}")}
-    if warm is not None:
-        out["active_set"] = torch.empty((n,), dtype=torch.int32, device=f"cuda:{device}")
+        del big_prev, o0["grf_body"]
+        out["active_set"] = torch.empty((sets * n,), dtype=torch.int32, device=dev)
+    del prevs
     if fused:
-        out["joint_tau"] = torch.empty((n, 12), dtype=torch.float64, device=f"cuda:{device}")
-    wall, evs = time_steps(ctl, dev_batch, warm, out, steps, warmup, dist)
-    solved = int((out["status"] == 0).sum().item())
-    return dict(wall=wall, event_s=evs, solved=solved, n=n, batch=batch, warm=warm is not None, out=out)
+        out["joint_tau"] = torch.empty((sets * n, 12), dtype=torch.float64, device=dev)
+    launches = []
+    for j in range(sets):
+        sl = slice(j * n, (j + 1) * n)
+        bj = {k: (v if k == "swing_state" else v[sl]) for k, v in big.items()}
+        oj = {k: v[sl] for k, v in out.items()}
+        launches.append(ctl.plan_batch(bj, warm=None if warm is None else warm[sl], out=oj)[0])
+    res = dict(n=n, sets=sets, batch=batch, warm=is_warm, out={k: v[:n] for k, v in out.items()})
+    if "cold" in protocols:
+        res["cold"] = time_launches(launches, steps, warmup, dist)
+    if "warm" in protocols:
+        res["warm_cache"] = time_launches(launches[:1], steps, warmup, dist)
+    res["solved"] = int((out["status"][:n] == 0).sum().item())
+    res["solved_all_sets"] = int((out["status"] == 0).sum().item()) if "cold" in protocols else res["solved"]
+    return res
 
 
 def host_cores():
@@ -162,23 +211,19 @@ def cpu_baseline(P, batch, budget_s=4.0):
 
 def batch_load_probe(q, P, device, nb=2097152, steps=10):
     """north_star: "achieved HBM GB/s on the batch load".  Same kernel with the solver iterations skipped
-    (QC_PROBE_BATCH_LOAD: load -> PD law / rotation log / Newton-Euler rhs -> output transform -> store;
+    (qc_set_tuning "probe_batch_load": load -> PD law / rotation log / Newton-Euler rhs -> output transform -> store;
     status = max_iter for every robot) on a batch four times the 256 MiB Infinity Cache.  The rows are
     262,144 config-5 robots tiled 8x on the device (their values do not matter without iterations)."""
     import torch
 
     from quadruped_control_amd import workloads as W
 
-    os.environ["QC_PROBE_BATCH_LOAD"] = "1"
-    try:
-        probe = q.BalanceController.from_params(P, device=device)
-    finally:
-        del os.environ["QC_PROBE_BATCH_LOAD"]
+    probe = q.BalanceController.from_params(P, device=device).set_tuning(probe_batch_load=1)
     base = q.to_device(W.config5(nb // 8), device)
     batch = {k: v.repeat(8, 1).contiguous() for k, v in base.items()}
     out = {"grf_body": torch.empty((nb, 12), dtype=torch.float64, device=f"cuda:{device}"),
            "status": torch.empty((nb,), dtype=torch.int32, device=f"cuda:{device}")}
-    _, evs = time_steps(probe, batch, None, out, steps, 2)
+    _, evs = time_launches([probe.plan_batch(batch, out=out)[0]], steps, 2)
     gbs = BYTES_PER_ROBOT_COLD * nb * steps / evs / 1e9
     return {"robots": nb, "bytes": BYTES_PER_ROBOT_COLD * nb, "us": evs / steps * 1e6, "achieved": gbs, "unit": "GB/s",
             "peak": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS,
@@ -211,8 +256,6 @@ def host_boundary(ctl, q):
            "config1_grf_RL": [float(v) for v in f[names[0]]]}
     exe = os.path.join(ROOT, "tests", "cpp", "adapter_test")  # built by __graft_entry__.build()
     if os.path.exists(exe):
-        import subprocess
-
         try:
             out = subprocess.run([exe], capture_output=True, text=True, timeout=120).stdout
             res["config1_cpp_adapter_latency_us"] = float(out.split("latency_us")[1].split()[0])
@@ -229,22 +272,38 @@ def host_boundary(ctl, q):
     return res
 
 
-def pmc_traffic(cfg, n):
-    """HBM bytes per launch from the newest committed PMC pass of this workload
-    (profiles/rNN_cfg<cfg>.json, produced by tools/profile_r.sh +
-    tools/summarize_profile.py: separate --pmc FETCH_SIZE / WRITE_SIZE passes,
-    FETCH_SIZE doubled per MI355X_MICROARCH.md).  None if no matching pass."""
+def pmc_traffic(cfg, n, sha):
+    """HBM bytes per launch from a committed PMC pass of this workload AND these kernel sources
+    (profiles/rNN_cfg<cfg>.json, produced by tools/profile_r.sh + tools/summarize_profile.py: separate --pmc
+    FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per MI355X_MICROARCH.md).  None if no matching pass:
+    counters cannot be read from inside the benchmarked process."""
     import glob
 
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_cfg{cfg}.json"))):
         try:
             d = json.load(open(f))
-            if d.get("bench_line", {}).get("config", {}).get("robots_per_gpu") == n and "traffic" in d:
+            bl = d.get("bench_line", {})
+            if bl.get("config", {}).get("robots_per_gpu") == n and bl.get("kernel_src_sha16") == sha and "traffic" in d:
                 best = (d["traffic"]["hbm_bytes_per_launch"], os.path.relpath(f, ROOT))
         except Exception:
             pass
     return best
+
+
+def rates(r, key, n, steps, bytes_per):
+    wall, evs = r[key]
+    return {"QPs_per_s": n * steps / wall, "avg_kernel_us": evs / steps * 1e6, "hbm_GBs": bytes_per * n * steps / evs / 1e9}
+
+
+def free_port():
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
 
 def main():
@@ -252,8 +311,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5])
-    ap.add_argument("--n", type=int, default=0, help="robots per GPU (default: the config's size)")
+    ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 4, 5], help="default: 2 at N = 1, 5 at N > 1")
+    ap.add_argument("--robots", type=int, default=0, dest="n",
+                    help="robots per GPU (default: the config's size; with --scaling strong the total is robots x N).  "
+                         "(Not '--n': torch.distributed.run's own parser would take that for an abbreviation of --nnodes.)")
+    ap.add_argument("--scaling", choices=["auto", "strong", "weak"], default="auto",
+                    help="N > 1: strong = config 5's fixed 2,097,152 robots sharded over the ranks (default); weak = --robots robots per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true", help="skip the informational runs of the other configs")
     ap.add_argument("--gather-results", action="store_true",
@@ -262,7 +325,21 @@ def main():
     ap.add_argument("--probe-batch-load", action="store_true",
                     help="time the load -> assemble -> store phase alone (no solver iterations) on 2,097,152 robots "
                          "(done by default together with the sweep)")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="development: qc_set_tuning override(s)")
     args = ap.parse_args()
+
+    one_dev = os.environ.get("QC_BENCH_ONE_DEVICE") == "1"  # test hook: all ranks on cuda:0, gloo instead of RCCL
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher: start the N ranks ourselves, one per GPU
+        import torch
+
+        have = torch.cuda.device_count()
+        if have < args.gpus and not one_dev:
+            sys.exit(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible")
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=env))
 
     import torch
 
@@ -271,15 +348,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} does not match WORLD_SIZE={world}")
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # QC_BENCH_ONE_DEVICE=1 (test hook): all ranks share cuda:0 and talk over gloo, so the
-        # multi-process path can be exercised on a 1-GPU box; the real run is one rank per GPU over RCCL.
-        one_dev = os.environ.get("QC_BENCH_ONE_DEVICE") == "1"
         if one_dev:
             local_rank = 0
             dist_mod.init_process_group("gloo")
@@ -292,15 +368,27 @@ def main():
 
     P = q.cheetah_params(mu=0.6)
     ctl = q.BalanceController.from_params(P, device=device)
-    cfg = args.config
-    n = args.n or CONFIG_N[cfg]
-    res = run_config(ctl, q, cfg, n, rank * n, args.steps, args.warmup, dist, device)
+    tune = {kv.split("=")[0]: float(kv.split("=")[1]) for kv in args.tune}
+    ctl.set_tuning(**tune)
+    cfg = args.config or (2 if world == 1 else 5)
+    scaling = args.scaling if args.scaling != "auto" else ("strong" if (world > 1 and cfg == 5 and not args.n) else "weak")
+    if scaling == "strong":
+        from quadruped_control_amd.sharding import shard_bounds
+
+        total = args.n * world if args.n else CONFIG5_TOTAL
+        lo, hi = shard_bounds(total, rank, world)
+        n, start = hi - lo, lo
+    else:
+        n = args.n or CONFIG_N[cfg]
+        start = rank * n
+    res = run_config(ctl, q, cfg, n, start, args.steps, args.warmup, dist, device)
 
     from quadruped_control_amd.sharding import reduce_counters
 
     on_gpu = dist is not None and dist.get_backend() == "nccl"
-    wall, solved_total, total_robots = reduce_counters(dist, res["wall"], res["solved"], n,
-                                                       device=f"cuda:{device}" if on_gpu else None)
+    rdev = f"cuda:{device}" if on_gpu else None
+    wall, solved_total, total_robots = reduce_counters(dist, res["cold"][0], res["solved"], n, device=rdev)
+    wall_warm, _, _ = reduce_counters(dist, res["warm_cache"][0], 0, 0, device=rdev)
 
     gather_s = None
     if dist is not None and args.gather_results:
@@ -311,9 +399,11 @@ def main():
         assert gathered.shape[0] == total_robots
 
     if rank == 0:
+        sha = kernel_src_sha16()
         bytes_per = BYTES_PER_ROBOT_WARM if res["warm"] else BYTES_PER_ROBOT_COLD
-        kernel_s = res["event_s"] / args.steps
+        kernel_s = res["cold"][1] / args.steps
         achieved = bytes_per * n / kernel_s / 1e9
+        info = ctl.query_launch(n, warm=res["warm"])
         line = {
             "metric": "friction-cone QPs/sec (12 vars, 4-foot stance) at 1/2/4/8 MI355X",
             "value": total_robots * args.steps / wall,
@@ -323,47 +413,71 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": wall / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": CONFIG_DESC[cfg].format(n=n), "robots_per_gpu": n, "global_batch": total_robots,
-                       "kernel": ctl.kernel_name, "parallelism": f"batch-shard x{world} (no data-path collective)"},
+                       "kernel": ctl.kernel_name, "lanes_per_robot": info["lanes_per_robot"], "kernel_mode": info["mode"],
+                       "resident_workgroups": info["resident_workgroups"],
+                       "parallelism": f"batch-shard x{world} (no data-path collective)",
+                       "cache_protocol": f"cold: the timed loop rotates through {res['sets']} distinct input/output sets "
+                                         f"({res['sets'] * bytes_per * n / 2**20:.0f} MiB in total) so every launch reads its inputs from HBM"},
             "solved_fraction": solved_total / total_robots,
+            "kernel_src_sha16": sha,
+            "warm_cache": {"value": total_robots * args.steps / wall_warm, "ms_per_step": wall_warm / args.steps * 1e3,
+                           "avg_kernel_us": res["warm_cache"][1] / args.steps * 1e6,
+                           "hbm_GBs": bytes_per * n * args.steps / res["warm_cache"][1] / 1e9,
+                           "what": "the same launch replayed on ONE resident set (inputs served by L2 / Infinity Cache)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "qc::balance_kernel", "bytes_per_launch": bytes_per * n,
                          "avg_kernel_us": kernel_s * 1e6,
-                         "note": "latency/FP64-VALU bound active-set solve; traffic from the PMC pass is in profiles/"},
+                         "note": "cold-cache protocol; latency / FP64-VALU bound active-set solve, see DESIGN.md 4"},
         }
+        if res["solved_all_sets"] != res["sets"] * n:
+            line["solved_fraction_all_sets"] = res["solved_all_sets"] / (res["sets"] * n)
         if gather_s is not None:
             line["result_gather"] = {"bytes_per_rank": n * 96, "seconds": gather_s, "GBs_per_rank": n * 96 * (world - 1) / gather_s / 1e9,
-                                     "what": "all_gather_into_tensor of the [n, 12] GRF blocks after the timed region (not part of value)"}
-        tr = pmc_traffic(cfg, n)
+                                     "what": "all-gather of the [n, 12] GRF blocks after the timed region (not part of value)"}
+        tr = pmc_traffic(cfg, n, sha)
         if tr is not None:
             line["roofline"]["traffic"] = tr[0]
-            line["roofline"]["traffic_source"] = tr[1] + " (rocprofv3 --pmc pass of this command, not re-measured in this run)"
+            line["roofline"]["traffic_source"] = tr[1] + " (rocprofv3 --pmc passes of this command on these kernel sources)"
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(P, res["batch"])
+        del res
+        torch.cuda.empty_cache()
         if world == 1 and not args.no_sweep:
             other = {}
+            k = max(5, min(args.steps, 50))
             for c in (2, 3, 4):
                 if c == cfg:
                     continue
-                r = run_config(ctl, q, c, CONFIG_N[c], 0, max(5, min(args.steps, 50)), 3, None, device)
-                k = max(5, min(args.steps, 50))
-                other[f"config{c}"] = {"robots": CONFIG_N[c], "QPs_per_s": CONFIG_N[c] * k / r["wall"],
-                                       "solved_fraction": r["solved"] / CONFIG_N[c],
-                                       "hbm_GBs": (BYTES_PER_ROBOT_WARM if r["warm"] else BYTES_PER_ROBOT_COLD) * CONFIG_N[c] * k / r["event_s"] / 1e9}
-            r = run_config(ctl, q, 2, CONFIG_N[2], 0, max(5, min(args.steps, 50)), 3, None, device, fused=True)
-            other["config2_fused_tick"] = {"robots": CONFIG_N[2], "QPs_per_s": CONFIG_N[2] * max(5, min(args.steps, 50)) / r["wall"],
+                r = run_config(ctl, q, c, CONFIG_N[c], 0, k, 3, None, device)
+                bp = BYTES_PER_ROBOT_WARM if r["warm"] else BYTES_PER_ROBOT_COLD
+                other[f"config{c}"] = {"robots": CONFIG_N[c], "solved_fraction": r["solved_all_sets"] / (r["sets"] * CONFIG_N[c]), "sets": r["sets"],
+                                       "cold_cache": rates(r, "cold", CONFIG_N[c], k, bp), "warm_cache": rates(r, "warm_cache", CONFIG_N[c], k, bp)}
+                del r
+                torch.cuda.empty_cache()
+            # the N = 1 point of the config-5 scaling curve: the full 2,097,152-robot batch on this GPU (1 GB: cold by size)
+            r = run_config(ctl, q, 5, CONFIG5_TOTAL, 0, 5, 2, None, device, protocols=("cold",))
+            other["config5_n1"] = {"robots": CONFIG5_TOTAL, "solved_fraction": r["solved"] / CONFIG5_TOTAL,
+                                   "cold_cache": rates(r, "cold", CONFIG5_TOTAL, 5, BYTES_PER_ROBOT_COLD),
+                                   "what": "N = 1 point of the strong-scaling curve that `bench.py --gpus N` (N > 1) continues"}
+            del r
+            torch.cuda.empty_cache()
+            r = run_config(ctl, q, 2, CONFIG_N[2], 0, k, 3, None, device, fused=True, protocols=("warm",))
+            other["config2_fused_tick"] = {"robots": CONFIG_N[2], "QPs_per_s": CONFIG_N[2] * k / r["warm_cache"][0],
                                            "solved_fraction": r["solved"] / CONFIG_N[2],
                                            "what": "joint_q -> forward kinematics -> control() -> clamp(J^T f) -> joint_tau in one launch (584 B/robot)"}
-            r = run_config(ctl, q, 3, CONFIG_N[3], 0, max(5, min(args.steps, 50)), 3, None, device, fused="full")
-            other["config3_full_tick"] = {"robots": CONFIG_N[3], "ticks_per_s": CONFIG_N[3] * max(5, min(args.steps, 50)) / r["wall"],
+            r = run_config(ctl, q, 3, CONFIG_N[3], 0, k, 3, None, device, fused="full", protocols=("warm",))
+            other["config3_full_tick"] = {"robots": CONFIG_N[3], "ticks_per_s": CONFIG_N[3] * k / r["warm_cache"][0],
                                           "solved_fraction": r["solved"] / CONFIG_N[3],
                                           "what": "joint states + COM state + gait phases -> complete joint torque command "
                                                   "(FK, contact rule, foothold planner, swing trajectories, IK, joint PD, QP, J^T) in one launch"}
+            del r
+            torch.cuda.empty_cache()
             line["other_configs"] = other
         if world == 1 and not args.no_sweep:
             line["host_boundary"] = host_boundary(ctl, q)

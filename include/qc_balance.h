@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define QC_ABI_VERSION 3
+#define QC_ABI_VERSION 4
 
 /* Replaces the constructor arguments of BalanceController
  * (balance_controller.hpp:85-88; defaults in commander_node.cpp:289-334 and
@@ -71,7 +71,7 @@ typedef struct qc_batch_in {
    * 1e-12 slack of math::almost_equal.  `gait_duty` [n] = stance_phase = t_stance / (t_swing + t_stance)
    * (gait.cpp:45) per robot, or NULL to use the value installed with qc_set_gait (default 0.8/0.98,
    * mit_cheetah_config.yaml:17-18). */
-  const double* gait_phase;
+  double* gait_phase;   /* read-only unless gait_dt is given (then IN/OUT, see below) */
   const double* gait_duty;
   /* ABI v2, optional; all three or none, need joint_q and joint_tau.  Swing-leg references as the reference's
    * FootTrajectoryManager::referenceState() returns them (WORLD frame foot position / velocity, [n][4][3], read
@@ -96,7 +96,8 @@ typedef struct qc_batch_in {
    * `gait_phase` is IN/OUT: at the start of the robot's tick its four phases advance the way
    * GaitScheduler::update does (gait.cpp:113-123): phase += 1 / (t_swing + t_stance) * dt, wrapped by
    * fmod(., 1), with the periods installed by qc_set_gait - and the contact rule, the foothold planner and
-   * the swing trajectories of this tick see the advanced phases.  The buffer behind `gait_phase` is written. */
+   * the swing trajectories of this tick see the advanced phases.  The buffer behind `gait_phase` is written
+ * (which is why that member is not const). */
   const double* gait_dt;
 } qc_batch_in;
 
@@ -181,7 +182,10 @@ int qc_control(qc_handle* h, const double* Rwb, const double* Rwb_d, const doubl
                const double* w_d, const double* feet, const uint8_t* stance, double* grf_body,
                int32_t* status);
 
-/* Kinematic model used by the joint_q / joint_tau extension; NULL restores the reference's constants. */
+/* Kinematic model used by the joint_q / joint_tau extension; NULL restores the reference's constants.
+ * qc_set_kinematics / qc_set_gait are configuration calls: they wait for all work on the device
+ * (hipDeviceSynchronize) before rewriting the constants, so no launch in flight - on any stream - sees a
+ * half-written copy. */
 void qc_default_kinematics(qc_kinematics* out);
 int qc_set_kinematics(qc_handle* h, const qc_kinematics* kin);
 /* Default stance_phase for qc_batch_in.gait_phase: t_stance / (t_swing + t_stance), GaitScheduler ctor gait.cpp:36-46. */
@@ -194,9 +198,36 @@ void qc_swing_state_init(struct qc_swing_state* states, size_t n);
 const char* qc_last_error(void);
 
 /* Introspection: which device formulation the handle selected
- * ("diagW-6x6" or "dense-12x12"), and ABI version. */
+ * ("diagW-6x6-uniform", "diagW-6x6" or "dense-12x12"), and ABI version. */
 const char* qc_kernel_name(const qc_handle* h);
 int qc_abi_version(void);
+
+/* ABI v4.  Which kernel instantiation a batch of n robots would run on (kin = joint_q given, warm = warm-start
+ * words given): lanes per robot, kernel mode (0 persistent waves with lane refill, 1 one fill per wave, 2 one fill
+ * and one wave per SIMD with register-resident constants), form (0 uniform 6x6, 1 general 6x6, 2 dense 12x12),
+ * robots per wave, grid size, and the workgroups of that kernel the device holds at once (the occupancy query the
+ * heuristics use). */
+typedef struct qc_launch_info {
+  int32_t lanes_per_robot;
+  int32_t mode;
+  int32_t form;
+  int32_t reserved;
+  int64_t chunk;
+  int64_t blocks;
+  int64_t resident_workgroups;
+  int64_t lds_bytes;
+} qc_launch_info;
+int qc_query_launch(qc_handle* h, size_t n, int kin, int warm, qc_launch_info* out);
+
+/* ABI v4.  Development / test interface: explicit overrides of the launch heuristics and solver constants (the
+ * library reads NO environment variables).  Keys: "group" (lanes per robot: 0 = heuristic, 1, 2, 4), "one_fill"
+ * (-1 heuristic, 0 persistent waves, 1 one-fill workgroups), "chunk" (robots per wave, 0 = heuristic),
+ * "wave_slots" (resident workgroups assumed, 0 = occupancy query), "refill_t", "rounds_cold", "rounds_warm",
+ * "force_general" / "force_dense" (run the more general formulation on weights that would allow the
+ * specialised one; same minimiser), "tol_d" (relative multiplier tolerance), "max_iter", "probe_batch_load"
+ * (1: skip the solver iterations - load, assemble, store only; every robot then reports QC_MAX_ITER).
+ * Calls that change device constants synchronise the device first.  Returns QC_ERR_INVALID for an unknown key. */
+int qc_set_tuning(qc_handle* h, const char* key, double value);
 
 #ifdef __cplusplus
 }

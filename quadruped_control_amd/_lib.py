@@ -44,8 +44,14 @@ class QcSwingState(C.Structure):
     _fields_ = [("leg_state", C.c_int32 * 4), ("has_traj", C.c_int32 * 4), ("p_start", C.c_double * 12), ("p_final", C.c_double * 12)]
 
 
+class QcLaunchInfo(C.Structure):
+    _fields_ = [("lanes_per_robot", C.c_int32), ("mode", C.c_int32), ("form", C.c_int32), ("reserved", C.c_int32),
+                ("chunk", C.c_int64), ("blocks", C.c_int64), ("resident_workgroups", C.c_int64), ("lds_bytes", C.c_int64)]
+
+
 EXPORTS = ("qc_create", "qc_destroy", "qc_control_batch", "qc_control_batch_host", "qc_control",
-           "qc_last_error", "qc_kernel_name", "qc_abi_version", "qc_default_kinematics", "qc_set_kinematics", "qc_set_gait", "qc_swing_state_init")
+           "qc_last_error", "qc_kernel_name", "qc_abi_version", "qc_default_kinematics", "qc_set_kinematics", "qc_set_gait", "qc_swing_state_init",
+           "qc_set_tuning", "qc_query_launch")
 
 _lib = None
 
@@ -98,6 +104,10 @@ def load():
     lib.qc_set_gait.restype = C.c_int
     lib.qc_swing_state_init.argtypes = [C.c_void_p, C.c_size_t]
     lib.qc_swing_state_init.restype = None
+    lib.qc_set_tuning.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+    lib.qc_set_tuning.restype = C.c_int
+    lib.qc_query_launch.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(QcLaunchInfo)]
+    lib.qc_query_launch.restype = C.c_int
     _lib = lib
     return lib
 

@@ -95,6 +95,24 @@ class BalanceController:
         if rc != _lib.QC_OK:
             raise RuntimeError(f"qc_set_gait failed ({rc}): {_lib.last_error()}")
 
+    def set_tuning(self, **kw):
+        """Development / test interface (qc_set_tuning): explicit overrides of the launch heuristics, e.g.
+        set_tuning(group=4, one_fill=0, chunk=128, force_general=1).  The library reads no environment variables."""
+        for key, value in kw.items():
+            rc = self._lib.qc_set_tuning(self._h, key.encode(), float(value))
+            if rc != _lib.QC_OK:
+                raise ValueError(f"qc_set_tuning({key}) failed ({rc}): {_lib.last_error()}")
+        return self
+
+    def query_launch(self, n, kin=False, warm=False):
+        """Which kernel instantiation a batch of n robots runs on: dict(lanes_per_robot, mode, form, chunk, blocks,
+        resident_workgroups, lds_bytes) - qc_query_launch."""
+        info = _lib.QcLaunchInfo()
+        rc = self._lib.qc_query_launch(self._h, int(n), int(bool(kin)), int(bool(warm)), C.byref(info))
+        if rc != _lib.QC_OK:
+            raise RuntimeError(f"qc_query_launch failed ({rc}): {_lib.last_error()}")
+        return {k: int(getattr(info, k)) for k, _ in info._fields_ if k != "reserved"}
+
     @property
     def kernel_name(self):
         return self._lib.qc_kernel_name(self._h).decode()
@@ -148,15 +166,9 @@ class BalanceController:
         return force_map
 
     # ------------------------------------------------------------------ batches
-    def control_batch(self, batch, warm=None, out=None, want_active_set=False, want_iterations=False, stream=None,
-                      want_torques=False):
-        """n robots, device-resident.  `batch`: dict of CUDA/HIP torch tensors
-        (float64, contiguous; 'stance' uint8 [n,4] or None) on this controller's
-        device.  Asynchronous on `stream` (default: torch's current stream).
-        Returns dict(grf_body [n,12], status [n] int32, active_set?, iterations?).
-        With batch['joint_q'] [n,12] the foot positions come from the reference's
-        forward kinematics (kinematics.cpp:81-103) and want_torques=True adds
-        joint_tau [n,12] = clamp(J^T f_body) for stance legs (kinematics.cpp:219-231)."""
+    def _marshal(self, batch, warm, out, want_active_set, want_iterations, want_torques):
+        """Validate the arguments of control_batch() and build the C structs; allocates `out` when it is None.
+        Launches nothing.  Returns (n, bi, bo, warm_ptr, out)."""
         import torch
 
         n = batch["x"].shape[0]
@@ -197,6 +209,16 @@ class BalanceController:
                 out["iterations"] = torch.empty((n,), dtype=torch.int32, device=dev)
             if want_torques:
                 out["joint_tau"] = torch.empty((n, 12), dtype=torch.float64, device=dev)
+        else:
+            for name, shape, dt in (("grf_body", n * 12, torch.float64), ("status", n, torch.int32), ("active_set", n, torch.int32),
+                                    ("iterations", n, torch.int32), ("joint_tau", n * 12, torch.float64)):
+                t = out.get(name)
+                if t is None:
+                    if name in ("grf_body", "status"):
+                        raise ValueError(f"out: '{name}' is required")
+                    continue
+                if t.dtype != dt or not t.is_contiguous() or t.numel() != shape or t.device != dev:
+                    raise ValueError(f"out['{name}']: need contiguous {dt} with {shape} elements on {dev}")
         bo = _lib.QcBatchOut()
         bo.grf_body = out["grf_body"].data_ptr()
         bo.status = out["status"].data_ptr()
@@ -205,10 +227,24 @@ class BalanceController:
         bo.joint_tau = out["joint_tau"].data_ptr() if "joint_tau" in out else None
         warm_ptr = None
         if warm is not None:
-            if warm.dtype != torch.int32 or warm.numel() != n or not warm.is_contiguous():
-                raise ValueError("warm: need contiguous int32 [n] (an active_set output)")
+            if warm.dtype != torch.int32 or warm.numel() != n or not warm.is_contiguous() or warm.device != dev:
+                raise ValueError("warm: need contiguous int32 [n] (an active_set output) on the controller's device")
             warm_ptr = warm.data_ptr()
-        s = stream if stream is not None else torch.cuda.current_stream(dev)
+        return n, bi, bo, warm_ptr, out
+
+    def control_batch(self, batch, warm=None, out=None, want_active_set=False, want_iterations=False, stream=None,
+                      want_torques=False):
+        """n robots, device-resident.  `batch`: dict of CUDA/HIP torch tensors
+        (float64, contiguous; 'stance' uint8 [n,4] or None) on this controller's
+        device.  Asynchronous on `stream` (default: torch's current stream).
+        Returns dict(grf_body [n,12], status [n] int32, active_set?, iterations?).
+        With batch['joint_q'] [n,12] the foot positions come from the reference's
+        forward kinematics (kinematics.cpp:81-103) and want_torques=True adds
+        joint_tau [n,12] = clamp(J^T f_body) for stance legs (kinematics.cpp:219-231)."""
+        import torch
+
+        n, bi, bo, warm_ptr, out = self._marshal(batch, warm, out, want_active_set, want_iterations, want_torques)
+        s = stream if stream is not None else torch.cuda.current_stream(torch.device("cuda", self.device))
         rc = self._lib.qc_control_batch(self._h, n, C.byref(bi), warm_ptr, C.byref(bo), C.c_void_p(s.cuda_stream))
         if rc != _lib.QC_OK:
             raise RuntimeError(f"qc_control_batch failed ({rc}): {_lib.last_error()}")
@@ -219,38 +255,24 @@ class BalanceController:
         """Validate and marshal the arguments of control_batch() once and return
         (launch, out): `launch()` is a single C call (qc_control_batch) that can be
         issued every tick without Python-side marshalling, e.g. in a simulation or
-        benchmark loop where the tensors are updated in place."""
+        benchmark loop where the tensors are updated in place.  Planning launches
+        NOTHING: the first launch() is the first tick (the gait clock and the swing
+        planner of a stateful batch are not advanced by plan_batch itself)."""
         import torch
 
-        n = batch["x"].shape[0]
-        dev = torch.device("cuda", self.device)
-        first = self.control_batch(batch, warm=warm, out=out, want_active_set=want_active_set,
-                                   want_iterations=want_iterations, stream=stream, want_torques=want_torques)  # validates + allocates
-        bi = _lib.QcBatchIn()
-        for name, _ in _IN_FIELDS + (("joint_q", 12),):
-            if batch.get(name) is not None:
-                setattr(bi, name, batch[name].data_ptr())
-        for name in ("stance", "gait_phase", "gait_duty", "gait_dt", "swing_pos", "swing_vel", "joint_qdot", "swing_state"):
-            if batch.get(name) is not None:
-                setattr(bi, name, batch[name].data_ptr())
-        bo = _lib.QcBatchOut()
-        bo.grf_body = first["grf_body"].data_ptr()
-        bo.status = first["status"].data_ptr()
-        bo.active_set = first["active_set"].data_ptr() if "active_set" in first else None
-        bo.iterations = first["iterations"].data_ptr() if "iterations" in first else None
-        bo.joint_tau = first["joint_tau"].data_ptr() if "joint_tau" in first else None
-        warm_ptr = warm.data_ptr() if warm is not None else None
-        s = stream if stream is not None else torch.cuda.current_stream(dev)
+        n, bi, bo, warm_ptr, out = self._marshal(batch, warm, out, want_active_set, want_iterations, want_torques)
+        self.query_launch(n, kin=batch.get("joint_q") is not None, warm=warm is not None)  # occupancy query done now, not inside a graph capture
+        s = stream if stream is not None else torch.cuda.current_stream(torch.device("cuda", self.device))
         fn, h, sp = self._lib.qc_control_batch, self._h, C.c_void_p(s.cuda_stream)
         bi_ref, bo_ref = C.byref(bi), C.byref(bo)
-        keep = (batch, warm, first, bi, bo)
+        keep = (batch, warm, out, bi, bo)
 
         def launch(_keep=keep):
             rc = fn(h, n, bi_ref, warm_ptr, bo_ref, sp)
             if rc != _lib.QC_OK:
                 raise RuntimeError(f"qc_control_batch failed ({rc}): {_lib.last_error()}")
 
-        return launch, first
+        return launch, out
 
     def control_batch_host(self, batch, warm=None, want_active_set=False, want_iterations=False, want_torques=False):
         """n robots, numpy (host) arrays in and out; PCIe-inclusive convenience path."""

@@ -38,12 +38,17 @@ namespace qc {
 // keeps the lanes busy although robots need between 1 and ~20 recalculations.
 //
 // LDS stock planes (see "Dense phases around the divergent solve" below).
-// SP = plane stride in doubles: 65, not 64, so that the lanes of one group (same
+// SP = plane stride in doubles = slots + 1 (odd), so that the lanes of one group (same
 // slot, planes 3*FPL apart) fall into different banks; the dense side
-// (plane[f][lane]) is conflict-free either way.
+// (plane[f][lane]) is conflict-free either way.  The stock is sized per kernel mode: a persistent wave
+// (MODE 0) restocks 64 robots at a time, a one-fill wave (MODE 1/2) only ever holds its 64/G robots, so its
+// stock is 64/G slots - 9.2 KB instead of 18 KB at G = 2, which is what lets more than two workgroups per
+// SIMD share the CU's 160 KB (the 92-VGPR one-fill kernels are register-good for five).
 enum { IN_B = 0, IN_R = 6, IN_FLAGS = 18, IN_IDX = 19, IN_PLANES = 20,
        OUT_F = 0, OUT_STAT = 12, OUT_WORD = 13, OUT_IDX = 14, OUT_PLANES = 15,
-       STOCK_PLANES = IN_PLANES + OUT_PLANES, SP = 65, STOCK_DOUBLES = ((STOCK_PLANES * SP + 63) / 64) * 64 };
+       STOCK_PLANES = IN_PLANES + OUT_PLANES };
+constexpr int stock_slots(int G, int MODE) { return MODE == 0 ? 64 : 64 / G; }
+constexpr int stock_doubles(int slots) { return ((STOCK_PLANES * (slots + 1) + 63) / 64) * 64; }
 
 template <class Eqp, bool KIN>
 struct Lane {
@@ -98,12 +103,16 @@ struct Lane {
   // body, the clamp of the fresh ones behind a wave-uniform branch); FIRST / STEADY = the one-fill modes, where
   // every robot of the wave is fresh in the first recalculation and none afterwards, so the first is peeled and
   // the steady body carries no clamp, no fresh/running selects and no ratio test for nothing.
+  // `live`: the lane's robot is still running.  The strided 4-lane kernels iterate every lane through a
+  // wave-uniform loop (MFMA sums read all 64 lanes), finished robots included: a finished robot recomputes
+  // the same f^ from the same working set (idempotent), so only what must not move once it has finished -
+  // working set, status, iteration count - is held back by `live`, instead of copying the whole lane state
+  // and selecting it back.  Callers whose EXEC mask already excludes finished robots pass true.
   enum { MIXED = 0, FIRST = 1, STEADY = 2 };
   template <int PHASE = MIXED, class PT>
-  QC_DEV bool iterate(const PT& P, Eqp& eqp) {
+  QC_DEV bool iterate(const PT& P, Eqp& eqp, const bool live = true) {
     double fh[3 * FPL], g[3 * FPL];
-    if (P.max_iter == 0) return true;  // measurement probe (QC_PROBE_BATCH_LOAD): load -> assemble -> store only
-    iters++;
+    iters += live ? 1 : 0;
     const bool pd = eqp.solve(P, Wr, C, stance, foot0, fh, g);
     const bool fresh = PHASE == FIRST ? true : (PHASE == STEADY ? false : !have_f);
     have_f = true;
@@ -172,16 +181,17 @@ struct Lane {
       sx = (bcode == b0 + 0) ? -1 : ((bcode == b0 + 1) ? 1 : ((wcode == w0 + 0) ? 0 : sx));
       sy = (bcode == b0 + 2) ? -1 : ((bcode == b0 + 3) ? 1 : ((wcode == w0 + 1) ? 0 : sy));
       sz = (bcode == b0 + 4) ? -1 : ((bcode == b0 + 5) ? 1 : ((wcode == w0 + 2) ? 0 : sz));
-      C.sx[i] = take_clamp ? Cc.sx[i] : sx;
-      C.sy[i] = take_clamp ? Cc.sy[i] : sy;
-      C.sz[i] = take_clamp ? Cc.sz[i] : sz;
+      C.sx[i] = live ? (take_clamp ? Cc.sx[i] : sx) : C.sx[i];
+      C.sy[i] = live ? (take_clamp ? Cc.sy[i] : sy) : C.sy[i];
+      C.sz[i] = live ? (take_clamp ? Cc.sz[i] : sz) : C.sz[i];
     }
-    if (!pd) { status = QC_NOT_PD; return true; }
-    if (at_fh && opt) { status = QC_SOLVED; return true; }
-    return iters >= P.max_iter;  // status stays QC_MAX_ITER
+    const bool solved = pd && at_fh && opt;
+    status = live ? (!pd ? (int)QC_NOT_PD : (solved ? (int)QC_SOLVED : status)) : status;  // otherwise it stays QC_MAX_ITER
+    return !pd || solved || iters >= P.max_iter;
   }
 
   // take the robot staged in `slot` of the wave's input stock into this lane's group
+  template <int SP>
   QC_DEV void load_from_stock(const double* __restrict__ sin, int slot, int member) {
     foot0 = member * FPL;
 #pragma unroll
@@ -211,6 +221,7 @@ struct Lane {
   }
 
   // park the finished robot's result in `slot` of the wave's output stock
+  template <int SP>
   QC_DEV void push_result(double* __restrict__ sout, int slot) const {
     uint32_t word = 0;
 #pragma unroll
@@ -286,7 +297,7 @@ QC_DEV void swing_plan(CParams& P, const BatchIn& in, long robot, int foot0, uin
 // FPL = 4: one lane assembles a whole robot (dense restock of a big batch);
 // FPL = 4/G: the G lanes of a group share a robot, each doing its own feet
 // (small fills, where latency matters more than lane efficiency).
-template <bool KIN, int FPL, bool STR = false>
+template <bool KIN, int FPL, bool STR, int SP>
 QC_DEV void assemble_to_stock(CParams& P, const BatchIn& in, const uint32_t* __restrict__ warm, long robot, int slot, int member,
                               double* __restrict__ sin) {
   constexpr int GG = 4 / FPL;
@@ -306,7 +317,7 @@ QC_DEV void assemble_to_stock(CParams& P, const BatchIn& in, const uint32_t* __r
     for (int i = 0; i < 4; i++) phs[i] = in.gait_phase[4 * robot + i];
     if (in.gait_dt) {  // GaitScheduler::update(dt), gait.cpp:113-123: the clock of this robot advances first
       const double step = 1.0 / (P.t_swing + P.t_stance) * in.gait_dt[robot];
-      double* wp = const_cast<double*>(in.gait_phase) + 4 * robot;
+      double* wp = in.gait_phase + 4 * robot;
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         phs[i] = fmod(phs[i] + step, 1.0);
@@ -341,7 +352,7 @@ QC_DEV void assemble_to_stock(CParams& P, const BatchIn& in, const uint32_t* __r
 }
 
 // output transform, BC.cpp:218-232: fb = -Rwb^T fw for stance legs; optional torque map
-template <bool KIN, int FPL>
+template <bool KIN, int FPL, int SP>
 QC_DEV void store_from_stock(CParams& P, const BatchIn& in, const BatchOut& out, const double* __restrict__ sout, int slot, int member) {
   const int foot0 = member * FPL;
   const long idx = __double_as_longlong(sout[OUT_IDX * SP + slot]);
@@ -425,7 +436,7 @@ QC_DEV void store_from_stock(CParams& P, const BatchIn& in, const BatchOut& out,
 }
 
 // dense assembly of the next (up to 64) robots of the chunk into the input stock; returns how many
-template <int G, bool KIN, bool STR = false>
+template <int G, bool KIN, bool STR, int SP>
 QC_DEV int restock(const DevParams* __restrict__ Pg, const BatchIn& in, const uint32_t* __restrict__ warm, long cursor, long end, int lane,
                    int member, double* __restrict__ sin) {
   const long left = end - cursor;
@@ -434,28 +445,28 @@ QC_DEV int restock(const DevParams* __restrict__ Pg, const BatchIn& in, const ui
     const int grp = lane_group<G, STR>(lane);
     if (grp < k) {
       CParams& P = *QC_PARAMS_HERE(Pg);
-      assemble_to_stock<KIN, 4 / G, STR>(P, in, warm, cursor + grp, grp, member, sin);
+      assemble_to_stock<KIN, 4 / G, STR, SP>(P, in, warm, cursor + grp, grp, member, sin);
     }
   } else if (lane < k) {
     CParams& P = *QC_PARAMS_HERE(Pg);
-    assemble_to_stock<KIN, 4>(P, in, warm, cursor + lane, lane, 0, sin);
+    assemble_to_stock<KIN, 4, false, SP>(P, in, warm, cursor + lane, lane, 0, sin);
   }
   __syncthreads();
   return k;
 }
 
 // store the robots parked in the output stock: one per lane, or one per lane group when there are few
-template <int G, bool KIN, bool STR = false>
+template <int G, bool KIN, bool STR, int SP>
 QC_DEV void flush_out(const DevParams* __restrict__ Pg, const BatchIn& in, const BatchOut& out, const double* __restrict__ sout, int out_n, int lane) {
   if (G > 1 && out_n <= 64 / G) {
     const int grp = lane_group<G, STR>(lane);
     if (grp < out_n) {
       CParams& P = *QC_PARAMS_HERE(Pg);
-      store_from_stock<KIN, 4 / G>(P, in, out, sout, grp, lane_member<G, STR>(lane));
+      store_from_stock<KIN, 4 / G, SP>(P, in, out, sout, grp, lane_member<G, STR>(lane));
     }
   } else if (lane < out_n) {
     CParams& P = *QC_PARAMS_HERE(Pg);
-    store_from_stock<KIN, 4>(P, in, out, sout, lane, 0);
+    store_from_stock<KIN, 4, SP>(P, in, out, sout, lane, 0);
   }
 }
 
@@ -463,7 +474,7 @@ QC_DEV void flush_out(const DevParams* __restrict__ Pg, const BatchIn& in, const
 // whose recalculation is 30 % shorter (620 vs 894 instructions) - and the wave waits for exactly these stragglers.
 // The running robots are re-packed through the (now idle) input stock and finish on the G = 4 body; `slot` is
 // where the robot's result goes in the output stock.  `bm` = ballot(busy), popcount <= 32.
-template <bool KIN, bool UNIFORM, class Lane2>
+template <bool KIN, bool UNIFORM, int SP, class Lane2>
 QC_DEV void finish_on_four_lanes(const DevParams* __restrict__ Pg, const Lane2& L, bool busy, unsigned long long bm, int slot, int member, int lane,
                                  double* __restrict__ sin, double* __restrict__ sout) {
   using Eqp4 = EqpDiagW<UNIFORM, 4, !QC_NO_STRIDED>;
@@ -472,6 +483,7 @@ QC_DEV void finish_on_four_lanes(const DevParams* __restrict__ Pg, const Lane2& 
   const int nb = __builtin_popcountll(bm) / 2;  // running robots
   if (nb == 0) return;
   constexpr int RS = 37;  // record stride in doubles (odd: the four lanes of a group read different banks)
+  static_assert(16 * RS <= IN_PLANES * SP, "the re-pack records live in the idle input stock");
   const int rank2 = __builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0)) / 2;
   __syncthreads();  // nobody reads the input stock any more
   if (busy) {
@@ -522,14 +534,13 @@ QC_DEV void finish_on_four_lanes(const DevParams* __restrict__ Pg, const Lane2& 
   }
   if constexpr (STR4) {
     while (__builtin_amdgcn_ballot_w64(busy4) != 0) {
-      Lane4 T = L4;
-      const bool done = T.template iterate<Lane4::STEADY>(*QC_PARAMS_HERE(Pg), eqp4);
-      if (busy4) { L4 = T; busy4 = !done; }
+      const bool done = L4.template iterate<Lane4::STEADY>(*QC_PARAMS_HERE(Pg), eqp4, busy4);
+      busy4 = busy4 && !done;
     }
   } else {
     while (busy4) busy4 = !L4.template iterate<Lane4::STEADY>(*QC_PARAMS_HERE(Pg), eqp4);
   }
-  if (g4 < nb) L4.push_result(sout, slot4);
+  if (g4 < nb) L4.template push_result<SP>(sout, slot4);
 }
 
 // MODE 0: persistent waves (chunks of many fills, lane refill).  MODE 1: the launch gives every wave at most one
@@ -540,6 +551,7 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
                                                                          const int refill_t) {
   constexpr int G = Eqp::G;
   extern __shared__ __attribute__((aligned(16))) double qc_lds[];  // [stock planes][64] (+ the dense form's 78 Hessian planes)
+  constexpr int SP = stock_slots(G, MODE) + 1;  // plane stride of this mode's stock
   double* const sin = qc_lds;
   double* const sout = qc_lds + IN_PLANES * SP;
   long cursor = (long)blockIdx.x * chunk;  // wave-uniform: next robot of this wave's chunk to assemble
@@ -553,7 +565,7 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
   Lane<Eqp, KIN> L;
   L.idx = -1;
   L.foot0 = member * (4 / G);
-  Eqp eqp(qc_lds + STOCK_DOUBLES + lane);
+  Eqp eqp(qc_lds + stock_doubles(stock_slots(G, MODE)) + lane);
   bool busy = false;  // group holds an unfinished robot
   QC_CLK_BEGIN();
   if constexpr (MODE != 0) {
@@ -564,9 +576,11 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
     if (cursor >= end) return;
     UConst uc;  // RESIDENT: the recalculation's constants live in VGPRs (no scalar load + wait per recalculation)
     if constexpr (RESIDENT) uc = load_uconst(*QC_PARAMS_HERE(Pg));
-    stock_n = restock<G, KIN, STR>(Pg, in, warm, cursor, end, lane, member, sin);
+    stock_n = restock<G, KIN, STR, SP>(Pg, in, warm, cursor, end, lane, member, sin);
     const int grp = lane_group<G, STR>(lane);
     busy = grp < stock_n;
+    // measurement probe (qc_set_tuning "probe_batch_load"): load -> assemble -> store only, no recalculation
+    const bool probe = QC_PARAMS_HERE(Pg)->max_iter == 0;
     using LaneT = Lane<Eqp, KIN>;
     if constexpr (STR) {
       // Strided layout: the group sums run on the matrix pipe, and an MFMA reads its operands from ALL 64 lanes
@@ -574,39 +588,39 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
       // EXEC.  So nothing here may run under a partial EXEC: every lane carries a robot (groups beyond the fill
       // shadow robot 0) through a wave-uniform loop, and only the lanes of running robots commit what a
       // recalculation produced.
-      L.load_from_stock(sin, busy ? grp : 0, member);
+      L.template load_from_stock<SP>(sin, busy ? grp : 0, member);
       eqp.setup(*QC_PARAMS_HERE(Pg), L.Wr, L.foot0);
+      busy = busy && !probe;
       {
-        LaneT T = L;
         bool done;
         if constexpr (RESIDENT) {
           pin_uconst(uc);
-          done = T.template iterate<LaneT::FIRST>(uc, eqp);
+          done = L.template iterate<LaneT::FIRST>(uc, eqp, busy);
         } else {
-          done = T.template iterate<LaneT::FIRST>(*QC_PARAMS_HERE(Pg), eqp);
+          done = L.template iterate<LaneT::FIRST>(*QC_PARAMS_HERE(Pg), eqp, busy);
         }
-        if (busy) { L = T; busy = !done; }
+        busy = busy && !done;
       }
       while (__builtin_amdgcn_ballot_w64(busy) != 0) {
-        LaneT T = L;
         bool done;
         if constexpr (RESIDENT) {
           pin_uconst(uc);
-          done = T.template iterate<LaneT::STEADY>(uc, eqp);
+          done = L.template iterate<LaneT::STEADY>(uc, eqp, busy);
         } else {
-          done = T.template iterate<LaneT::STEADY>(*QC_PARAMS_HERE(Pg), eqp);
+          done = L.template iterate<LaneT::STEADY>(*QC_PARAMS_HERE(Pg), eqp, busy);
         }
-        if (busy) { L = T; busy = !done; }
+        busy = busy && !done;
       }
-      if (grp < stock_n) L.push_result(sout, grp);
+      if (grp < stock_n) L.template push_result<SP>(sout, grp);
       __syncthreads();
-      flush_out<Eqp::G, KIN, STR>(Pg, in, out, sout, stock_n, lane);
+      flush_out<Eqp::G, KIN, STR, SP>(Pg, in, out, sout, stock_n, lane);
       return;
     }
     if (busy) {
-      L.load_from_stock(sin, grp, member);
+      L.template load_from_stock<SP>(sin, grp, member);
       eqp.setup(*QC_PARAMS_HERE(Pg), L.Wr, L.foot0);
     }
+    busy = busy && !probe;
     QC_CLK(0, 2);
     if (busy) {  // every robot of a one-fill wave is fresh exactly once: the clamp step is peeled
       if constexpr (RESIDENT) {
@@ -622,8 +636,8 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
         if (busy) busy = !L.template iterate<LaneT::STEADY>(*QC_PARAMS_HERE(Pg), eqp);
         bm = __builtin_amdgcn_ballot_w64(busy);
       }
-      if (!busy && grp < stock_n) L.push_result(sout, grp);  // finished in the two-lane layout
-      finish_on_four_lanes<KIN, Eqp::kUniform>(Pg, L, busy, bm, grp, member, lane, sin, sout);
+      if (!busy && grp < stock_n) L.template push_result<SP>(sout, grp);  // finished in the two-lane layout
+      finish_on_four_lanes<KIN, Eqp::kUniform, SP>(Pg, L, busy, bm, grp, member, lane, sin, sout);
     } else {
       while (busy) {
         if constexpr (RESIDENT) {
@@ -633,11 +647,11 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
           busy = !L.template iterate<LaneT::STEADY>(*QC_PARAMS_HERE(Pg), eqp);
         }
       }
-      if (grp < stock_n) L.push_result(sout, grp);
+      if (grp < stock_n) L.template push_result<SP>(sout, grp);
     }
     QC_CLK(7, 8);
     __syncthreads();
-    flush_out<Eqp::G, KIN, STR>(Pg, in, out, sout, stock_n, lane);
+    flush_out<Eqp::G, KIN, STR, SP>(Pg, in, out, sout, stock_n, lane);
     QC_CLK_END(8);
     return;
   }
@@ -645,7 +659,7 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
   // inside the loop) it needs no spills: batches that fit one fill per wave
   // never execute the in-loop copy.
   if (cursor < end) {
-    stock_n = restock<G, KIN>(Pg, in, warm, cursor, end, lane, member, sin);
+    stock_n = restock<G, KIN, false, SP>(Pg, in, warm, cursor, end, lane, member, sin);
     cursor += stock_n;
   }
   QC_CLK(0, 1);
@@ -655,7 +669,7 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
     const long avail = (end - cursor) + (long)(stock_n - stock_next);
     if (avail > 0 && (n_free >= refill_t || busy_mask == 0)) {
       if (stock_next == stock_n) {
-        stock_n = restock<G, KIN>(Pg, in, warm, cursor, end, lane, member, sin);
+        stock_n = restock<G, KIN, false, SP>(Pg, in, warm, cursor, end, lane, member, sin);
         stock_next = 0;
         cursor += stock_n;
       }
@@ -663,7 +677,7 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
       const int take = n_free < have ? n_free : have;
       const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(~busy_mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)~busy_mask, 0)) / G;
       if (!busy && rank < take) {
-        L.load_from_stock(sin, stock_next + rank, member);
+        L.template load_from_stock<SP>(sin, stock_next + rank, member);
         CParams& P = *QC_PARAMS_HERE(Pg);
         eqp.setup(P, L.Wr, L.foot0);
         busy = true;
@@ -677,7 +691,8 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
       asm volatile("; QC_ITER_BEGIN");
       QC_CLK(1, 2);
       CParams& P = *QC_PARAMS_HERE(Pg);
-      fin = L.iterate(P, eqp);
+      if (P.max_iter == 0) fin = true;  // measurement probe: load -> assemble -> store only (wave-uniform branch)
+      else fin = L.iterate(P, eqp);
       QC_CLK(7, 1);
       asm volatile("; QC_ITER_END");
     }
@@ -686,13 +701,13 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
       const int n_fin = __builtin_popcountll(fin_mask) / G;
       if (out_n + n_fin > 64) {  // dense flush of the output stock, one robot per lane
         __syncthreads();
-        flush_out<Eqp::G, KIN>(Pg, in, out, sout, out_n, lane);
+        flush_out<Eqp::G, KIN, false, SP>(Pg, in, out, sout, out_n, lane);
         __syncthreads();
         out_n = 0;
       }
       if (fin) {
         const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(fin_mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fin_mask, 0)) / G;
-        L.push_result(sout, out_n + rank);
+        L.template push_result<SP>(sout, out_n + rank);
         busy = false;
       }
       out_n += n_fin;
@@ -700,24 +715,34 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
   }
   __syncthreads();
   QC_CLK(1, 8);
-  flush_out<Eqp::G, KIN>(Pg, in, out, sout, out_n, lane);
+  flush_out<Eqp::G, KIN, false, SP>(Pg, in, out, sout, out_n, lane);
   QC_CLK_END(8);
 }
 
 }  // namespace qc
 
 // =============================================================== host / C ABI
+typedef void (*qc_kernel_fn)(const qc::DevParams*, long, qc::BatchIn, const uint32_t*, qc::BatchOut, long, int);
+
 struct qc_handle {
   int device;
+  int cus;                  // compute units of the device
   qc::DevParams dp;
-  qc::DevParams* d_params;  // device copy of dp (immutable after qc_create)
+  qc::DevParams* d_params;  // device copy of dp (rewritten only by the qc_set_* calls, after a device synchronise)
   bool diag_w;   // W diagonal -> 6x6 formulation
   bool uniform;  // additionally S diagonal and W = w*I -> scalar-constant specialisation
-  int wave_slots;       // CUs x 4 SIMDs x resident waves per SIMD
-  int refill_t;         // parked lanes that trigger a refill
-  long chunk_override;  // development knob (QC_CHUNK)
-  int group_override;   // development knob (QC_GROUP): lanes per robot
-  bool no_single;       // development knob (QC_NO_SINGLE): never take the one-fill-per-wave variants
+  // launch heuristics (defaults from measurements; qc_set_tuning overrides them)
+  int refill_t;            // parked lanes that trigger a refill (persistent waves)
+  double rounds_cold;      // cold batches up to rounds x (robots resident as one-fill workgroups) run one-fill
+  double rounds_warm;      // the same for warm-started batches
+  long chunk_override;     // > 0: robots per wave
+  int group_override;      // 1, 2, 4: lanes per robot
+  int one_fill_override;   // 0: never (persistent waves), 1: always, -1: heuristic
+  int wave_slots_override; // > 0: resident workgroups assumed for every kernel instead of the occupancy query
+  int min_waves;           // development builds (QC_EXPERIMENTAL_OCC): register cap of the one-fill kernels, waves per SIMD
+  // resident workgroups per kernel instantiation (hipOccupancyMaxActiveBlocksPerMultiprocessor x CUs), filled lazily
+  struct { qc_kernel_fn fn; size_t lds; long resident; } occ[40];
+  int n_occ;
   // staging buffers for the host-pointer entry points
   void* stage;
   size_t stage_bytes;
@@ -797,6 +822,133 @@ static void sextic_basis(double* basis) {
     for (int k = 0; k < 3; k++) basis[3 * j + k] = M[j][7 + k];
 }
 
+// Rewrites the device copy of the constants.  Launches in flight - on any stream, non-blocking ones included -
+// may still be reading the old copy through scalar loads, so the device is drained first; the copy itself is
+// synchronous.  Setters are configuration calls, not per-tick calls.
+static int upload_params(qc_handle* h) {
+  QC_HIP(hipSetDevice(h->device));
+  QC_HIP(hipDeviceSynchronize());
+  QC_HIP(hipMemcpy(h->d_params, &h->dp, sizeof(qc::DevParams), hipMemcpyHostToDevice));
+  return QC_OK;
+}
+
+// ---------------------------------------------------------------- launch planning
+// One wave per 64-thread block; a group of G lanes per robot.  The group width trades latency for throughput:
+// G = 4 (foot per lane) has the shortest recalculation (536 instructions per wave against 894 at G = 2 and 1330
+// at G = 1) and is used while four lanes per robot still fit the resident waves - such a batch cannot fill the
+// chip anyway and the slowest robot's serial chain is what is timed; G = 2 costs the same lane-instructions per
+// robot as G = 1, halves the latency and suffers less from iteration-count divergence, so it serves every larger
+// batch of the 6x6 forms.  Batches that fit `rounds` times the resident one-fill workgroups run as one-fill
+// workgroups (the hardware scheduler does the refill); larger ones as persistent waves walking contiguous chunks.
+enum { QC_FORM_UNIFORM = 0, QC_FORM_GENERAL = 1, QC_FORM_DENSE = 2 };
+#ifndef QC_ROUNDS_COLD
+#define QC_ROUNDS_COLD 1.0
+#endif
+#ifndef QC_ROUNDS_WARM
+#define QC_ROUNDS_WARM 6.0
+#endif
+
+template <class EQP, int MINW, int MODE>
+static qc_kernel_fn kernel_of(bool kin) {
+  return kin ? (qc_kernel_fn)qc::balance_kernel<EQP, true, MINW, MODE> : (qc_kernel_fn)qc::balance_kernel<EQP, false, MINW, MODE>;
+}
+// the kernel instantiation for (form, lanes per robot, mode); mode 2 exists for the uniform G = 4 form only
+static qc_kernel_fn kernel_for(int form, int G, int mode, bool kin, int minw = 2) {
+  using namespace qc;
+  constexpr bool STR = !QC_NO_STRIDED;
+#ifdef QC_EXPERIMENTAL_OCC  // development builds: register-capped one-fill instantiations of the uniform form (tools/occ_scan.py)
+  if (form == QC_FORM_UNIFORM && mode == 1 && minw > 2) {
+    if (G == 4) return minw >= 4 ? kernel_of<EqpDiagW<true, 4, STR>, 4, 1>(kin) : kernel_of<EqpDiagW<true, 4, STR>, 3, 1>(kin);
+    if (G == 2) return minw >= 4 ? kernel_of<EqpDiagW<true, 2>, 4, 1>(kin) : kernel_of<EqpDiagW<true, 2>, 3, 1>(kin);
+  }
+#endif
+  (void)minw;
+  if (form == QC_FORM_DENSE) return mode ? kernel_of<EqpDense, 1, 1>(kin) : kernel_of<EqpDense, 1, 0>(kin);
+  if (form == QC_FORM_GENERAL) {
+    if (G == 4) return mode ? kernel_of<EqpDiagW<false, 4, STR>, 2, 1>(kin) : kernel_of<EqpDiagW<false, 4>, 2, 0>(kin);
+    if (G == 2) return mode ? kernel_of<EqpDiagW<false, 2>, 2, 1>(kin) : kernel_of<EqpDiagW<false, 2>, 2, 0>(kin);
+    return kernel_of<EqpDiagW<false, 1>, 2, 0>(kin);
+  }
+  if (G == 4) return mode == 2 ? kernel_of<EqpDiagW<true, 4, STR>, 2, 2>(kin) : (mode ? kernel_of<EqpDiagW<true, 4, STR>, 2, 1>(kin) : kernel_of<EqpDiagW<true, 4>, 2, 0>(kin));
+  if (G == 2) return mode ? kernel_of<EqpDiagW<true, 2>, 2, 1>(kin) : kernel_of<EqpDiagW<true, 2>, 2, 0>(kin);
+  return kernel_of<EqpDiagW<true, 1>, 2, 0>(kin);
+}
+static size_t lds_for(int form, int G, int mode) {
+  const size_t stock = (size_t)qc::stock_doubles(qc::stock_slots(G, mode)) * sizeof(double);
+  return form == QC_FORM_DENSE ? stock + 78 * 64 * sizeof(double) : stock;
+}
+// workgroups of this kernel the device holds at once (registers, LDS and the 32-waves-per-CU cap, as the runtime sees them)
+static long resident_workgroups(qc_handle* h, qc_kernel_fn fn, size_t lds) {
+  if (h->wave_slots_override > 0) return h->wave_slots_override;
+  for (int i = 0; i < h->n_occ; i++)
+    if (h->occ[i].fn == fn && h->occ[i].lds == lds) return h->occ[i].resident;
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64, lds) != hipSuccess || per_cu <= 0) per_cu = 4;
+  const long r = (long)per_cu * h->cus;
+  if (h->n_occ < (int)(sizeof(h->occ) / sizeof(h->occ[0]))) {
+    h->occ[h->n_occ].fn = fn; h->occ[h->n_occ].lds = lds; h->occ[h->n_occ].resident = r;
+    h->n_occ++;
+  }
+  return r;
+}
+
+struct qc_launch_plan {
+  qc_kernel_fn fn;
+  size_t lds;
+  unsigned blocks;
+  long chunk;
+  int refill_t, G, mode;
+  long resident;
+};
+
+static int plan_launch(qc_handle* h, long n, bool kin, bool warm, qc_launch_plan* lp) {
+  const int form = !h->diag_w ? QC_FORM_DENSE : (h->uniform ? QC_FORM_UNIFORM : QC_FORM_GENERAL);
+  int G = 1;
+  if (form != QC_FORM_DENSE) {
+    const long cap4 = resident_workgroups(h, kernel_for(form, 4, 1, kin, h->min_waves), lds_for(form, 4, 1)) * 16;
+    G = n <= cap4 ? 4 : 2;
+    if (h->group_override) G = h->group_override;
+  }
+  const long rpw = 64 / G;  // robots per wave fill
+  // G = 1 of the 6x6 forms has no one-fill instantiation (development width only)
+  const bool can_one_fill = form == QC_FORM_DENSE || G > 1;
+  bool one_fill = false;
+  long resident = 0;
+  if (can_one_fill) {
+    resident = resident_workgroups(h, kernel_for(form, G, 1, kin, h->min_waves), lds_for(form, G, 1));
+    const double rounds = warm ? h->rounds_warm : h->rounds_cold;
+    one_fill = (double)n <= rounds * (double)(resident * rpw);
+    // The joint_q / joint_tau variants carry the kinematics through the persistent loop and spill 300-400 B per
+    // lane there; as one-fill workgroups they stay at 68 B and win at every size (complete tick, 1 M robots:
+    // 1570 -> 941 us).
+    if (kin && G > 1) one_fill = true;
+    if (h->one_fill_override >= 0) one_fill = h->one_fill_override != 0;
+    if (h->chunk_override > 0) one_fill = h->chunk_override <= rpw;
+  }
+  int mode = 0;
+  long chunk;
+  if (one_fill) {
+    chunk = h->chunk_override > 0 ? h->chunk_override : rpw;
+    const long blocks = (n + chunk - 1) / chunk;
+    // one wave per SIMD is enough: the recalculation's constants stay resident in VGPRs (uniform G = 4 form)
+    mode = (form == QC_FORM_UNIFORM && G == 4 && blocks <= (long)h->cus * 4) ? 2 : 1;
+  } else {
+    resident = resident_workgroups(h, kernel_for(form, G, 0, kin), lds_for(form, G, 0));
+    chunk = rpw;
+    if (n > rpw * resident) chunk = ((n + resident - 1) / resident + 15) / 16 * 16;
+    if (h->chunk_override > 0) chunk = h->chunk_override;
+  }
+  lp->fn = kernel_for(form, G, mode, kin, h->min_waves);
+  lp->lds = lds_for(form, G, mode);
+  lp->blocks = (unsigned)((n + chunk - 1) / chunk);
+  lp->chunk = chunk;
+  lp->refill_t = h->refill_t > 0 ? (h->refill_t + G - 1) / G : 1;
+  lp->G = G;
+  lp->mode = mode;
+  lp->resident = resident;
+  return QC_OK;
+}
+
 extern "C" {
 
 const char* qc_last_error(void) { return g_err.c_str(); }
@@ -849,9 +1001,7 @@ int qc_set_kinematics(qc_handle* h, const qc_kinematics* kin) {
   std::memcpy(h->dp.planner_hip, k.planner_hip, sizeof(k.planner_hip));
   h->dp.planner_k = k.planner_k;
   h->dp.swing_height = k.swing_height;
-  QC_HIP(hipSetDevice(h->device));
-  QC_HIP(hipMemcpy(h->d_params, &h->dp, sizeof(qc::DevParams), hipMemcpyHostToDevice));  // synchronous: no launch races it
-  return QC_OK;
+  return upload_params(h);
 }
 
 int qc_set_gait(qc_handle* h, double t_swing, double t_stance) {
@@ -860,9 +1010,7 @@ int qc_set_gait(qc_handle* h, double t_swing, double t_stance) {
   h->dp.stance_phase = t_stance / (t_swing + t_stance);  // gait.cpp:45
   h->dp.t_swing = t_swing;
   h->dp.t_stance = t_stance;
-  QC_HIP(hipSetDevice(h->device));
-  QC_HIP(hipMemcpy(h->d_params, &h->dp, sizeof(qc::DevParams), hipMemcpyHostToDevice));
-  return QC_OK;
+  return upload_params(h);
 }
 
 int qc_create(const qc_params* p, int device, qc_handle** out) {
@@ -888,7 +1036,6 @@ int qc_create(const qc_params* p, int device, qc_handle** out) {
     for (int j = 0; j < i; j++)
       if (std::fabs(p->W[12 * i + j] - p->W[12 * j + i]) > 1e-12 * (p->W[12 * i + i] + p->W[12 * j + j]))
         return fail(QC_ERR_INVALID, "qc_create: W must be symmetric");
-  if (const char* e = std::getenv("QC_FORCE_DENSE")) if (e[0] == '1') diag = false;  // test/bench knob: dense path on a diagonal W
 
   qc_handle* h = new (std::nothrow) qc_handle();
   if (!h) return fail(QC_ERR_INVALID, "qc_create: out of memory");
@@ -923,7 +1070,6 @@ int qc_create(const qc_params* p, int device, qc_handle** out) {
       if (i != j && p->S[6 * i + j] != 0.0) uni = false;
   for (int i = 1; i < 12; i++)
     if (p->W[12 * i + i] != p->W[0]) uni = false;
-  if (const char* e = std::getenv("QC_FORCE_GENERAL")) if (e[0] == '1') uni = false;  // test knob
   h->uniform = uni;
   for (int i = 0; i < 6; i++) d.Vd[i] = d.V[6 * i + i];
   d.w_u = p->W[0];
@@ -958,26 +1104,80 @@ int qc_create(const qc_params* p, int device, qc_handle** out) {
   // 1e-12 gave 0.2 N = 2e-3 relative in the parameter fuzz; 1e-13 ... 1e-15 all agree with the NNLS restatement
   // and change neither the recalculation counts of 1 M robots nor anything else measurable).
   d.tol_d = 1e-14;
-  if (const char* e = std::getenv("QC_TOL_D")) d.tol_d = std::atof(e);  // development knob
   d.max_iter = p->max_iter > 0 ? p->max_iter : 200;
-  if (const char* e = std::getenv("QC_PROBE_BATCH_LOAD")) if (e[0] == '1') d.max_iter = 0;  // bench.py --probe-batch-load
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete h; return fail(QC_ERR_HIP, "qc_create: hipGetDeviceProperties failed"); }
-  h->wave_slots = prop.multiProcessorCount * 4 * (h->diag_w ? 2 : 1);
+  h->cus = prop.multiProcessorCount;
   h->refill_t = 16;
+  h->rounds_cold = QC_ROUNDS_COLD;
+  h->rounds_warm = QC_ROUNDS_WARM;
   h->chunk_override = 0;
-  if (const char* e = std::getenv("QC_REFILL_T")) h->refill_t = std::atoi(e);    // development knobs
-  if (const char* e = std::getenv("QC_CHUNK")) h->chunk_override = std::atol(e);
-  if (const char* e = std::getenv("QC_WAVE_SLOTS")) h->wave_slots = std::atoi(e);
   h->group_override = 0;
-  if (const char* e = std::getenv("QC_GROUP")) { const int g = std::atoi(e); if (g == 1 || g == 2 || g == 4) h->group_override = g; }
-  h->no_single = std::getenv("QC_NO_SINGLE") != nullptr;
+  h->one_fill_override = -1;
+  h->wave_slots_override = 0;
+  h->min_waves = 2;
+  h->n_occ = 0;
   if (hipSetDevice(device) != hipSuccess || hipMalloc((void**)&h->d_params, sizeof(qc::DevParams)) != hipSuccess ||
       hipMemcpy(h->d_params, &h->dp, sizeof(qc::DevParams), hipMemcpyHostToDevice) != hipSuccess) {
     delete h;
     return fail(QC_ERR_HIP, "qc_create: could not upload the controller constants");
   }
   *out = h;
+  return QC_OK;
+}
+
+int qc_set_tuning(qc_handle* h, const char* key, double value) {
+  if (!h || !key) return fail(QC_ERR_INVALID, "qc_set_tuning: null argument");
+  const std::string k(key);
+  bool params = false;
+  if (k == "group") {
+    const int g = (int)value;
+    if (g != 0 && g != 1 && g != 2 && g != 4) return fail(QC_ERR_INVALID, "qc_set_tuning: group is 0 (heuristic), 1, 2 or 4");
+    h->group_override = g;
+  } else if (k == "one_fill") h->one_fill_override = value < 0 ? -1 : (value != 0 ? 1 : 0);
+  else if (k == "chunk") h->chunk_override = value > 0 ? (long)value : 0;
+  else if (k == "wave_slots") h->wave_slots_override = value > 0 ? (int)value : 0;
+  else if (k == "min_waves") h->min_waves = value > 2 ? (int)value : 2;
+  else if (k == "refill_t") h->refill_t = value > 0 ? (int)value : 16;
+  else if (k == "rounds_cold") h->rounds_cold = value;
+  else if (k == "rounds_warm") h->rounds_warm = value;
+  else if (k == "force_general") {  // general 6x6 form on uniform weights (same minimiser)
+    bool uni = h->diag_w;
+    for (int i = 0; i < 6; i++)
+      for (int j = 0; j < 6; j++)
+        if (i != j && h->dp.S[6 * i + j] != 0.0) uni = false;
+    for (int i = 1; i < 12; i++)
+      if (h->dp.w[i] != h->dp.w[0]) uni = false;
+    h->uniform = value != 0 ? false : uni;
+  } else if (k == "force_dense") {  // dense 12x12 form on a diagonal W (same minimiser)
+    bool diag = true;
+    for (int i = 0; i < 12; i++)
+      for (int j = 0; j < 12; j++)
+        if (i != j && h->dp.W[12 * i + j] != 0.0) diag = false;
+    h->diag_w = value != 0 ? false : diag;
+  } else if (k == "tol_d") { h->dp.tol_d = value; params = true; }
+  else if (k == "max_iter") { h->dp.max_iter = value > 0 ? (int)value : 200; params = true; }
+  else if (k == "probe_batch_load") {
+    // measurement probe: load -> assemble -> store only (every robot reports QC_MAX_ITER); value 0 restores 200
+    h->dp.max_iter = value != 0 ? 0 : 200; params = true;
+  } else return fail(QC_ERR_INVALID, "qc_set_tuning: unknown key '" + k + "'");
+  return params ? upload_params(h) : QC_OK;
+}
+
+int qc_query_launch(qc_handle* h, size_t n, int kin, int warm, qc_launch_info* out) {
+  if (!h || !out) return fail(QC_ERR_INVALID, "qc_query_launch: null argument");
+  QC_HIP(hipSetDevice(h->device));
+  qc_launch_plan lp;
+  const int rc = plan_launch(h, (long)(n ? n : 1), kin != 0, warm != 0, &lp);
+  if (rc != QC_OK) return rc;
+  out->lanes_per_robot = lp.G;
+  out->mode = lp.mode;
+  out->form = !h->diag_w ? QC_FORM_DENSE : (h->uniform ? QC_FORM_UNIFORM : QC_FORM_GENERAL);
+  out->reserved = 0;
+  out->chunk = lp.chunk;
+  out->blocks = lp.blocks;
+  out->resident_workgroups = resident_workgroups(h, lp.fn, lp.lds);
+  out->lds_bytes = (int64_t)lp.lds;
   return QC_OK;
 }
 
@@ -1010,59 +1210,10 @@ int qc_control_batch(qc_handle* h, size_t n, const qc_batch_in* in, const uint32
                  in->gait_phase, in->gait_duty, in->swing_pos, in->swing_vel, in->joint_qdot,
                  reinterpret_cast<qc::SwingState*>(in->swing_state), in->gait_dt};
   qc::BatchOut bo{out->grf_body, out->status, out->active_set, out->iterations, out->joint_tau};
-  // One wave per 64-thread block; a group of G lanes per robot.  The group
-  // width trades latency for throughput: G = 4 (foot per lane) cuts the serial
-  // length of one recalculation (707 instead of 1330 instructions) and is used
-  // while 4 lanes per robot still fit the resident waves; G = 2 costs the same
-  // lane-instructions per robot as G = 1 (the replicated 6x6 solve is paid for
-  // by the halved per-foot work), halves the latency and suffers less from
-  // iteration-count divergence (32 robots per wave), so it serves every larger
-  // batch.  G = 1 remains for the general (non-uniform weights) form.
-  // Batches larger than the chip holds at once run as persistent waves, each
-  // walking a contiguous chunk with lane refill.
-  int G = 1;
-  if (h->diag_w) {
-    const long lanes = (long)h->wave_slots * 64;
-    G = (long)n * 4 <= lanes ? 4 : 2;
-    if (h->group_override) G = h->group_override;
-  }
-  const long rpw = 64 / G;  // robots per wave fill
-  const long slots = (long)h->wave_slots;
-  long chunk = rpw;
-  if ((long)n > rpw * slots) chunk = (((long)n + slots - 1) / slots + 15) / 16 * 16;
-  // The joint_q / joint_tau variants carry the kinematics through the persistent loop and spill 300-400 B per
-  // lane there; as one-fill workgroups (the hardware scheduler does the "refill") they stay at 68 B and win at
-  // every size (complete tick, 1 M robots: 1570 -> 941 us).  The plain path is the opposite (config 4: 124 vs 78 us).
-  if (kin && G > 1) chunk = rpw;
-  // Warm-started ticks finish in ~1 recalculation per robot: nothing for lane refill to balance, and up to six
-  // rounds of one-fill workgroups beat the persistent waves (262 144 robots: 53 vs 58 us; from ~450 k robots on
-  // the dense 64-robot assembly of the persistent kernel wins again).
-  if (warm && G == 2 && (long)n <= 6 * rpw * slots) chunk = rpw;
-  if (h->chunk_override > 0) chunk = h->chunk_override;
-  const unsigned blocks = (unsigned)(((long)n + chunk - 1) / chunk);
-  const int refill_t = h->refill_t > 0 ? (h->refill_t + G - 1) / G : 1;
-  const bool single = chunk <= rpw && !h->no_single;  // every wave gets at most one fill
-  const hipStream_t st = (hipStream_t)stream;
-#define QC_LAUNCH(EQP, MINW, LDS, ...)                                                                                               \
-  do {                                                                                                                              \
-    if (kin) qc::balance_kernel<EQP, true, MINW, ##__VA_ARGS__><<<dim3(blocks), dim3(64), LDS, st>>>(h->d_params, (long)n, bi, warm, bo, chunk, refill_t);  \
-    else qc::balance_kernel<EQP, false, MINW, ##__VA_ARGS__><<<dim3(blocks), dim3(64), LDS, st>>>(h->d_params, (long)n, bi, warm, bo, chunk, refill_t);     \
-  } while (0)
-  constexpr size_t kStock = qc::STOCK_DOUBLES * sizeof(double);
-  if (!h->diag_w && single) QC_LAUNCH(qc::EqpDense, 1, kStock + 78 * 64 * sizeof(double), 1);
-  else if (!h->diag_w) QC_LAUNCH(qc::EqpDense, 1, kStock + 78 * 64 * sizeof(double));
-  else if (!h->uniform && G == 4 && single) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<false, 4, !QC_NO_STRIDED>), 2, kStock, 1);
-  else if (!h->uniform && G == 4) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<false, 4>), 2, kStock);
-  else if (!h->uniform && G == 2 && single) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<false, 2>), 2, kStock, 1);
-  else if (!h->uniform && G == 2) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<false, 2>), 2, kStock);
-  else if (!h->uniform) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<false, 1>), 2, kStock);
-  else if (G == 4 && single && (long)blocks * 2 <= slots) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<true, 4, !QC_NO_STRIDED>), 2, kStock, 2);  // one wave per SIMD is enough; the 256-register bound keeps the MFMA results out of AGPRs
-  else if (G == 4 && single) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<true, 4, !QC_NO_STRIDED>), 2, kStock, 1);
-  else if (G == 4) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<true, 4>), 2, kStock);
-  else if (G == 2 && single) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<true, 2>), 2, kStock, 1);
-  else if (G == 2) QC_LAUNCH(QC_COMMA(qc::EqpDiagW<true, 2>), 2, kStock);
-  else QC_LAUNCH(QC_COMMA(qc::EqpDiagW<true, 1>), 2, kStock);
-#undef QC_LAUNCH
+  qc_launch_plan lp;
+  const int rc = plan_launch(h, (long)n, kin, warm != nullptr, &lp);
+  if (rc != QC_OK) return rc;
+  lp.fn<<<dim3(lp.blocks), dim3(64), lp.lds, (hipStream_t)stream>>>(h->d_params, (long)n, bi, warm, bo, lp.chunk, lp.refill_t);
   QC_HIP(hipGetLastError());
   return QC_OK;
 }
@@ -1130,7 +1281,7 @@ int qc_control_batch_host(qc_handle* h, size_t n, const qc_batch_in* in, const u
   din.feet = (const double*)put(in->feet, n * 12 * 8);  // may be absent when joint_q is given
   din.stance = (const uint8_t*)put(in->stance, n * 4);
   din.joint_q = (const double*)put(in->joint_q, n * 12 * 8);
-  din.gait_phase = (const double*)put(in->gait_phase, n * 4 * 8);
+  din.gait_phase = (double*)put(in->gait_phase, n * 4 * 8);
   din.gait_duty = (const double*)put(in->gait_duty, n * 8);
   din.gait_dt = (const double*)put(in->gait_dt, n * 8);
   din.swing_pos = (const double*)put(in->swing_pos, n * 12 * 8);
@@ -1155,7 +1306,7 @@ int qc_control_batch_host(qc_handle* h, size_t n, const qc_batch_in* in, const u
   get(out->iterations, dout.iterations, n * 4);
   get(out->joint_tau, dout.joint_tau, n * 12 * 8);
   get(in->swing_state, din.swing_state, n * sizeof(qc_swing_state));
-  if (in->gait_dt) get(const_cast<double*>(in->gait_phase), din.gait_phase, n * 4 * 8);  // the advanced clock
+  if (in->gait_dt) get(in->gait_phase, din.gait_phase, n * 4 * 8);  // the advanced clock
   QC_HIP(cerr);
   if (!pinned) QC_HIP(hipStreamSynchronize(h->stream));
   return QC_OK;

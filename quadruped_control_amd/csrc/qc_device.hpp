@@ -1,12 +1,15 @@
 // qc_device.hpp - device-side building blocks of the batched balance controller
-// (gfx950 / CDNA4, wave64, FP64 VALU; no MFMA on purpose: the per-robot
-// matrices are 6x6 / 12x12 and every lane group owns a different robot).
+// (gfx950 / CDNA4, wave64, FP64 VALU).  The arithmetic of the QP is not GEMM-shaped
+// (per-robot 6x6 / 12x12 matrices, every lane group owns a different robot), so it stays
+// on the vector ALU; the matrix pipe is used only as a cross-lane reduction network
+// (v_mfma_f64_4x4x4f64 with an all-ones A operand, see group_sum).
 //
-// Execution model: a GROUP of G adjacent lanes (G = 1, 2 or 4) owns one robot
+// Execution model: a GROUP of G lanes (G = 1, 2 or 4) owns one robot
 // (one QP instance); each lane of the group owns 4/G feet.  Per-foot work
 // (face coefficients, contributions to the 6x6 system, forces, ratio test,
 // multipliers) is split across the group, the small dense solve is replicated,
-// and partial sums / minima are combined with DPP quad permutes (no LDS).
+// and partial sums / minima are combined without LDS: DPP quad permutes for adjacent
+// lanes, MFMA sums and row swaps for the stride-16 layout of the 4-lane kernels.
 // G = 1 maximises throughput per instruction, G = 4 minimises the serial
 // latency of one working-set recalculation (small batches, stragglers).
 // All per-robot state lives in VGPRs with compile-time indexing; batch inputs
@@ -116,7 +119,7 @@ struct BatchIn {
   const double *Rwb, *Rwb_d, *x, *xdot, *w, *x_d, *xdot_d, *w_d, *feet;
   const uint8_t* stance;
   const double* joint_q;
-  const double* gait_phase;
+  double* gait_phase;  // written when gait_dt is given
   const double* gait_duty;
   const double* swing_pos;
   const double* swing_vel;
@@ -225,6 +228,16 @@ QC_DEV double group_sum(double v) {
     return v;
   }
 }
+// group sum plus a group-uniform addend: in the strided layout the addend is the MFMA's C operand
+template <int G, bool S = false>
+QC_DEV double group_sum_add(double v, double addend) {
+  if constexpr (S) {
+#ifndef QC_SUM_BY_SWAPS
+    return __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, v, addend, 0, 0, 0);
+#endif
+  }
+  return group_sum<G, S>(v) + addend;
+}
 template <int G, bool S = false>
 QC_DEV double group_min(double v) {
   if constexpr (S) {
@@ -274,6 +287,16 @@ QC_DEV double rsqrt_nr(double d) {
   t = d * y;
   e = __builtin_fma(-t, y, 1.0);
   y = __builtin_fma(y * 0.5, e, y);
+  return y;
+}
+
+QC_DEV double rcp_nr(double d) {
+  // v_rcp_f64 seed (2^-24) + two Newton steps: 2^-48, then full FP64 accuracy (tools/ubench_rsq.hip)
+  double y = __builtin_amdgcn_rcp(d);
+  double e = __builtin_fma(-d, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-d, y, 1.0);
+  y = __builtin_fma(y, e, y);
   return y;
 }
 
@@ -698,111 +721,108 @@ QC_DEV bool eqp_diagw(const PT& P, const FootW (&lane_w)[4 / G], const Wrench<4 
   double M[21];
   // packed lower triangle index r*(r+1)/2 + c
 #define MI(r, c) ((r) * ((r) + 1) / 2 + (c))
-#pragma unroll
-  for (int k = 0; k < 21; k++) M[k] = 0.0;
   double rhs[6];
-#pragma unroll
-  for (int k = 0; k < 6; k++) rhs[k] = 0.0;
 
   // Face coefficients: with one foot per lane (G = 4) they stay live across the
   // factorisation (12 VGPRs); with more feet per lane they are
   // recomputed in pass 2 instead, registers matter more there.
   constexpr bool KEEP = FPL <= 1;
   FootCoef kc[FPL];
-  // pass 1: this lane's part of sum_i A~_i B_i^-1 A~_i^T and of A p
+  // pass 1: this lane's part of sum_i A~_i B_i^-1 A~_i^T and of A p.  The first foot of the lane writes the
+  // entries, later feet accumulate (no 0 + x adds, which strict FP cannot fold).
 #pragma unroll
   for (int i = 0; i < FPL; i++) {
+    const bool first = i == 0;  // compile-time after unrolling
     const bool st = (stance >> (foot0 + i)) & 1u;
     const FootW fwt = weights(i);
     const FootCoef k = foot_coef<UNIFORM>(P, fwt, C.sx[i], C.sy[i], C.sz[i], st);
     if (KEEP) kc[i] = k;
     const double rx = Wr.r[i][0], ry = Wr.r[i][1], rz = Wr.r[i][2];
-    double q[6];
+    double q[6], tq[6];
     q[0] = k.mx; q[1] = k.my; q[2] = 1.0;
     q[3] = ry - rz * k.my;
     q[4] = rz * k.mx - rx;
     q[5] = rx * k.my - ry * k.mx;
 #pragma unroll
-    for (int c = 0; c < 6; c++) rhs[c] = __builtin_fma(k.fzfix, q[c], rhs[c]);
-    // x slot column (1,0,0, 0, rz, -ry)
-    {
-      const double t4 = k.ix * rz, t5 = -k.ix * ry;
-      M[MI(0, 0)] += k.ix;
-      M[MI(4, 0)] += t4;
-      M[MI(5, 0)] += t5;
-      M[MI(4, 4)] = __builtin_fma(t4, rz, M[MI(4, 4)]);
-      M[MI(5, 4)] = __builtin_fma(t5, rz, M[MI(5, 4)]);
-      M[MI(5, 5)] = __builtin_fma(t5, -ry, M[MI(5, 5)]);
-    }
-    // y slot column (0,1,0, -rz, 0, rx)
-    {
-      const double t3 = -k.iy * rz, t5 = k.iy * rx;
-      M[MI(1, 1)] += k.iy;
-      M[MI(3, 1)] += t3;
-      M[MI(5, 1)] += t5;
-      M[MI(3, 3)] = __builtin_fma(t3, -rz, M[MI(3, 3)]);
-      M[MI(5, 3)] = __builtin_fma(t5, -rz, M[MI(5, 3)]);
-      M[MI(5, 5)] = __builtin_fma(t5, rx, M[MI(5, 5)]);
-    }
-    // z slot column q
-#pragma unroll
     for (int c = 0; c < 6; c++) {
-      const double tq = k.iz * q[c];
-#pragma unroll
-      for (int r = c; r < 6; r++) M[MI(r, c)] = __builtin_fma(q[r], tq, M[MI(r, c)]);
+      rhs[c] = first ? k.fzfix * q[c] : __builtin_fma(k.fzfix, q[c], rhs[c]);
+      tq[c] = k.iz * q[c];  // z slot column q, scaled
     }
+    // x slot column (1,0,0, 0, rz, -ry) and y slot column (0,1,0, -rz, 0, rx)
+    const double t4 = k.ix * rz, t5 = -k.ix * ry;
+    const double t3 = -k.iy * rz, u5 = k.iy * rx;
+#define QC_ACC0(r, c) M[MI(r, c)] = first ? q[r] * tq[c] : __builtin_fma(q[r], tq[c], M[MI(r, c)])
+#define QC_ACC1(r, c, base) M[MI(r, c)] = first ? __builtin_fma(q[r], tq[c], (base)) : __builtin_fma(q[r], tq[c], M[MI(r, c)] + (base))
+    QC_ACC1(0, 0, k.ix);
+    QC_ACC0(1, 0); QC_ACC1(1, 1, k.iy);
+    QC_ACC0(2, 0); QC_ACC0(2, 1); QC_ACC0(2, 2);
+    QC_ACC0(3, 0); QC_ACC1(3, 1, t3); QC_ACC0(3, 2); QC_ACC1(3, 3, -t3 * rz);
+    QC_ACC1(4, 0, t4); QC_ACC0(4, 1); QC_ACC0(4, 2); QC_ACC0(4, 3); QC_ACC1(4, 4, t4 * rz);
+    QC_ACC1(5, 0, t5); QC_ACC1(5, 1, u5); QC_ACC0(5, 2); QC_ACC1(5, 3, -u5 * rz); QC_ACC1(5, 4, t5 * rz);
+    QC_ACC1(5, 5, __builtin_fma(u5, rx, -t5 * ry));
+#undef QC_ACC0
+#undef QC_ACC1
   }
   QC_CLK_PIN(M); QC_CLK_PIN(rhs);
   QC_CLK(2, 3);
-  // combine the group's partial sums, then add S^-1 and -b
+  // combine the group's partial sums; S^-1 and -b ride along as the addend of the reduction (the C operand of
+  // the MFMA in the strided layout: no dependent add behind the matrix pipe)
 #pragma unroll
   for (int r = 0; r < 6; r++) {
 #pragma unroll
     for (int c = 0; c <= r; c++) {
-      double s = group_sum<G, S>(M[MI(r, c)]);
-      if constexpr (!UNIFORM) s += P.V[6 * r + c];
-      else if (r == c) s += P.Vd[r];  // S^-1 is diagonal here: nothing to add off the diagonal
-      M[MI(r, c)] = s;
+      if constexpr (!UNIFORM) M[MI(r, c)] = group_sum_add<G, S>(M[MI(r, c)], P.V[6 * r + c]);
+      else if (r == c) M[MI(r, c)] = group_sum_add<G, S>(M[MI(r, c)], P.Vd[r]);  // S^-1 is diagonal here
+      else M[MI(r, c)] = group_sum<G, S>(M[MI(r, c)]);
     }
-    rhs[r] = group_sum<G, S>(rhs[r]) - Wr.b[r];
+    rhs[r] = group_sum_add<G, S>(rhs[r], -Wr.b[r]);
   }
   QC_CLK_PIN(M); QC_CLK_PIN(rhs);
   QC_CLK(3, 4);
-  // Cholesky M = L L^T (in place; diagonal holds 1/L_kk)
+  // M = L D L^T (in place: unit lower L below the diagonal, 1/d_k on it).  No square roots: the pivot's
+  // reciprocal is v_rcp_f64 + two Newton steps (5 dependent operations instead of the 7 of rsq + Newton), and
+  // the triangular solves carry no scaling on their serial chain.
   bool ok = true;
 #pragma unroll
   for (int k = 0; k < 6; k++) {
+    double wk[6];  // w_m = L_km d_m
     double d = M[MI(k, k)];
 #pragma unroll
-    for (int m = 0; m < k; m++) d = __builtin_fma(-M[MI(k, m)], M[MI(k, m)], d);
+    for (int m = 0; m < k; m++) {
+      wk[m] = M[MI(k, m)];               // still unscaled: u_km = L_km d_m
+      M[MI(k, m)] = wk[m] * M[MI(m, m)]; // L_km
+      d = __builtin_fma(-M[MI(k, m)], wk[m], d);
+    }
     ok = ok && (d > 0.0);
-    const double rinv = rsqrt_nr(d);
-    M[MI(k, k)] = rinv;
+    M[MI(k, k)] = rcp_nr(d);
+    // rows below: u_rk = M_rk - sum_m u_rm L_km (kept unscaled until row r becomes the pivot row)
 #pragma unroll
     for (int r = k + 1; r < 6; r++) {
       double t = M[MI(r, k)];
 #pragma unroll
       for (int m = 0; m < k; m++) t = __builtin_fma(-M[MI(r, m)], M[MI(k, m)], t);
-      M[MI(r, k)] = t * rinv;
+      M[MI(r, k)] = t;
     }
   }
   QC_CLK_PIN(M);
   QC_CLK(4, 5);
-  // solve L L^T v = rhs
+  // solve L D L^T v = rhs
   double v[6];
 #pragma unroll
   for (int k = 0; k < 6; k++) {
     double t = rhs[k];
 #pragma unroll
     for (int m = 0; m < k; m++) t = __builtin_fma(-M[MI(k, m)], v[m], t);
-    v[k] = t * M[MI(k, k)];
+    v[k] = t;
   }
 #pragma unroll
-  for (int k = 5; k >= 0; k--) {
+  for (int k = 0; k < 6; k++) v[k] *= M[MI(k, k)];
+#pragma unroll
+  for (int k = 4; k >= 0; k--) {
     double t = v[k];
 #pragma unroll
     for (int m = k + 1; m < 6; m++) t = __builtin_fma(-M[MI(m, k)], v[m], t);
-    v[k] = t * M[MI(k, k)];
+    v[k] = t;
   }
 #undef MI
   QC_CLK_PIN(v);

@@ -32,20 +32,35 @@ def reduce_counters(dist, wall_s, solved, robots, device=None):
 
 
 def gather_results(dist, grf_shard):
-    """Optional result collection: all-gather of the per-rank [n, 12] GRF blocks, outside the timed
-    hot path.  Returns (gathered tensor [world * n, 12], seconds).  RCCL over xGMI when the tensor lives on a GPU
-    and the backend is "nccl"; the CPU tests run it over gloo."""
+    """Optional result collection: all-gather of the per-rank [n_r, 12] GRF blocks, outside the timed
+    hot path.  Returns (gathered tensor [sum n_r, 12] in rank order, seconds).  Shards may be uneven (shard_bounds
+    gives the first n % world ranks one robot more): the sizes are exchanged first and the blocks are gathered into
+    a padded buffer, then trimmed.  RCCL over xGMI when the tensor lives on a GPU and the backend is "nccl"; the CPU
+    tests run it over gloo."""
     import time
 
     import torch
 
     world = dist.get_world_size()
-    out = torch.empty((world * grf_shard.shape[0], grf_shard.shape[1]), dtype=grf_shard.dtype, device=grf_shard.device)
+    dev = grf_shard.device
+    sizes = torch.zeros(world, dtype=torch.int64, device=dev)
+    sizes[dist.get_rank()] = grf_shard.shape[0]
+    dist.all_reduce(sizes, op=dist.ReduceOp.SUM)
+    sizes = [int(v) for v in sizes.tolist()]
+    pad = max(sizes)
+    cols = grf_shard.shape[1]
+    mine = grf_shard.contiguous()
+    if mine.shape[0] != pad:
+        mine = torch.cat([mine, torch.zeros((pad - mine.shape[0], cols), dtype=mine.dtype, device=dev)])
+    out = torch.empty((world * pad, cols), dtype=grf_shard.dtype, device=dev)
     if grf_shard.is_cuda:
         torch.cuda.synchronize()
     dist.barrier()
     t0 = time.perf_counter()
-    dist.all_gather_into_tensor(out, grf_shard.contiguous())
+    dist.all_gather_into_tensor(out, mine)
     if grf_shard.is_cuda:
         torch.cuda.synchronize()
-    return out, time.perf_counter() - t0
+    dt = time.perf_counter() - t0
+    if any(sz != pad for sz in sizes):
+        out = torch.cat([out[r * pad:r * pad + sizes[r]] for r in range(world)])
+    return out, dt

@@ -12,10 +12,8 @@ P = q.cheetah_params(0.6)
 b = W.config3(n, seed=0x5EED00AA)
 d = q.to_device(b)
 res = {}
-for name, env in (("G2/G4 default", {}), ("G1", {"QC_GROUP": "1"}), ("G4", {"QC_GROUP": "4"}), ("general6x6", {"QC_FORCE_GENERAL": "1"}), ("dense12x12", {"QC_FORCE_DENSE": "1"})):
-    for k, v in env.items(): os.environ[k] = v
-    ctl = q.BalanceController.from_params(P)
-    for k in env: del os.environ[k]
+for name, env in (("G2/G4 default", {}), ("G1", {"group": 1}), ("G4", {"group": 4}), ("general6x6", {"force_general": 1}), ("dense12x12", {"force_dense": 1})):
+    ctl = q.BalanceController.from_params(P).set_tuning(**env)
     o = ctl.control_batch(d, want_iterations=True)
     torch.cuda.synchronize()
     assert int((o["status"] != 0).sum()) == 0, name

@@ -65,7 +65,11 @@ def _gather_worker(rank, world, port, n, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from quadruped_control_amd.sharding import gather_results
 
-    shard = torch.arange(n * 12, dtype=torch.float64).reshape(n, 12) + 1000.0 * rank
+    from quadruped_control_amd.sharding import shard_bounds
+
+    lo, hi = shard_bounds(n * world + (1 if n % 2 else 0), rank, world)  # odd n: uneven shards (rank 0 holds one robot more)
+    m = hi - lo
+    shard = torch.arange(m * 12, dtype=torch.float64).reshape(m, 12) + 1000.0 * rank
     out, secs = gather_results(dist, shard)
     if rank == 0:
         q.put((out.numpy(), secs))
@@ -73,9 +77,14 @@ def _gather_worker(rank, world, port, n, q):
     dist.destroy_process_group()
 
 
-def test_result_gather_gloo():
-    """SURVEY 8e optional result collection: equal-sized per-rank GRF blocks all-gathered in rank order."""
-    n, world = 64, 2
+import pytest
+
+
+@pytest.mark.parametrize("n", [64, 33])
+def test_result_gather_gloo(n):
+    """SURVEY 8e optional result collection: per-rank GRF blocks all-gathered in rank order; n = 33 gives the
+    uneven shards shard_bounds() produces when the batch does not divide (34 + 33 robots)."""
+    world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -86,6 +95,8 @@ def test_result_gather_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    base = np.arange(n * 12, dtype=np.float64).reshape(n, 12)
-    np.testing.assert_array_equal(out, np.concatenate([base, base + 1000.0]))
+    n0 = n + (1 if n % 2 else 0)
+    b0 = np.arange(n0 * 12, dtype=np.float64).reshape(n0, 12)
+    b1 = np.arange(n * 12, dtype=np.float64).reshape(n, 12) + 1000.0
+    np.testing.assert_array_equal(out, np.concatenate([b0, b1]))
     assert secs >= 0.0

@@ -1,7 +1,9 @@
-"""-m gpu: bench.py keeps its contract (one JSON line on rank 0 with roofline + cpu_baseline at N = 1; the
-torch.distributed.run launch with N > 1 ranks shards the batch and reduces the counters)."""
+"""-m gpu: bench.py keeps its contract (one JSON line on rank 0 with roofline + cpu_baseline at N = 1; `--gpus N`
+starts N ranks by itself or checks the launcher's WORLD_SIZE; N > 1 shards config 5's fixed batch and reduces the
+counters over the process group - RCCL when the box has the GPUs, gloo on one device otherwise)."""
 import json
 import os
+import socket
 import subprocess
 import sys
 
@@ -18,6 +20,14 @@ def _last_json(out):
     lines = [l for l in out.strip().splitlines() if l.startswith("{")]
     assert len(lines) == 1, out[-2000:]
     return json.loads(lines[0])
+
+
+def _free_port():
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    return port
 
 
 def test_bench_line_single_gpu(built):
@@ -37,22 +47,64 @@ def test_bench_line_single_gpu(built):
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "QPs/s" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
     assert d["value"] > 10 * cb["value"]
+    # cold-cache protocol: rotating sets cover more than 512 MiB; the one-set replay is reported next to it
+    assert "rotates through 269 distinct" in d["config"]["cache_protocol"]  # 512 MiB / (488 B x 4096) + 1
+    assert d["warm_cache"]["value"] > 0 and d["warm_cache"]["avg_kernel_us"] > 0
+    assert len(d["kernel_src_sha16"]) == 16
+
+
+def test_gpus_flag_must_match_the_launcher(built):
+    """bench.py --gpus 2 under a launcher that made a different world fails instead of printing n_gpus: 1."""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-sweep", "--no-cpu-baseline"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "does not match WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def _check_two_rank_line(d, total):
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["global_batch"] == total
+    assert d["config"]["robots_per_gpu"] == total // 2 and d["config"]["workload"].startswith("config5")
+    assert d["solved_fraction"] == 1.0 and d["value"] > 0
+    assert abs(d["value"] - total / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert "cpu_baseline" not in d  # rank 0 at N = 1 only
 
 
 def test_bench_two_ranks_torchrun(built):
-    """The N > 1 launch the driver uses, on this box's single GPU (QC_BENCH_ONE_DEVICE: both ranks on cuda:0, gloo
-    for the barrier / counter reduction instead of RCCL)."""
-    import socket
-
-    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    """The N > 1 launch the driver uses (torch.distributed.run), on this box's single GPU (QC_BENCH_ONE_DEVICE: both
+    ranks on cuda:0, gloo for the barrier / counter reduction instead of RCCL): config 5's fixed batch, sharded."""
     env = dict(os.environ, QC_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "3", "--gather-results"]
+           "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "10", "--warmup", "2", "--gather-results",
+           "--scaling", "strong", "--robots", "65536"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _last_json(r.stdout)
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 8192 and d["config"]["robots_per_gpu"] == 4096
-    assert d["solved_fraction"] == 1.0 and d["value"] > 0
-    assert abs(d["value"] - 8192 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
-    assert "cpu_baseline" not in d  # rank 0 at N = 1 only
-    assert d["result_gather"]["bytes_per_rank"] == 4096 * 96 and d["result_gather"]["seconds"] > 0
+    _check_two_rank_line(d, 131072)
+    assert d["result_gather"]["bytes_per_rank"] == 65536 * 96 and d["result_gather"]["seconds"] > 0
+
+
+def test_bench_self_launch_two_ranks(built):
+    """`python bench.py --gpus 2` without a launcher starts its own two ranks (one-device hook on a 1-GPU box)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(QC_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "5", "--warmup", "1", "--scaling", "strong", "--robots", "32768"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    _check_two_rank_line(_last_json(r.stdout), 65536)
+
+
+def test_bench_two_ranks_rccl(built):
+    """Two ranks on two GPUs over RCCL (backend "nccl"): config 5's full 2,097,152-robot batch, one shard per
+    GPU.  Runs whenever the box has at least two devices; the driver's 1-GPU box skips it."""
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL)")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "QC_BENCH_ONE_DEVICE")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "10", "--warmup", "2", "--gather-results"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    _check_two_rank_line(d, 2097152)
+    assert d["result_gather"]["seconds"] > 0

@@ -1,0 +1,175 @@
+"""-m gpu: oracle parity over EVERY kernel instantiation the launch planner can pick.
+
+The planner (plan_launch, qc_balance.hip) chooses by formulation (uniform 6x6 / general 6x6 / dense 12x12),
+lanes per robot (1 / 2 / 4) and kernel mode (0 persistent waves with lane refill, 1 one fill per wave, 2 one fill
+with register-resident constants).  Each test forces one branch with qc_set_tuning, checks through qc_query_launch
+that this branch is the one that runs, and compares with the C oracle on config-3 inputs (mixed 2/3/4-foot contact
+states), cold and warm-started; the joint_q / joint_tau (KIN) instantiations run the fused tick against the oracle's
+composition.  Cold runs of all forms must also take the same working-set path (identical iteration counts).
+Reference semantics held: balance_controller.cpp:152-153 (QP data), 274-330 (constraint rows).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-6  # of max|GRF| per robot; north_star's bar is 1e-4
+FORMS = {"uniform": {}, "general": {"force_general": 1}, "dense": {"force_dense": 1}}
+FORM_ID = {"uniform": 0, "general": 1, "dense": 2}
+# (form, lanes per robot, mode) -> (tuning, robots): every branch of kernel_for()
+CASES = []
+for form in ("uniform", "general"):
+    CASES += [(form, 1, 0, dict(group=1, chunk=256), 8192),
+              (form, 2, 0, dict(group=2, chunk=256), 8192),
+              (form, 2, 1, dict(group=2, one_fill=1), 8192),
+              (form, 4, 0, dict(group=4, chunk=128), 8192),
+              (form, 4, 1, dict(group=4, one_fill=1), 20480 if form == "uniform" else 8192)]
+CASES += [("uniform", 4, 2, dict(group=4, one_fill=1), 8192),
+          ("dense", 1, 0, dict(chunk=256), 8192),
+          ("dense", 1, 1, dict(one_fill=1), 8192)]
+IDS = [f"{f}-G{g}-mode{m}" for f, g, m, _, _ in CASES]
+
+
+@pytest.fixture(scope="module")
+def q(built):
+    import quadruped_control_amd as q
+
+    return q
+
+
+_cache = {}
+
+
+def _inputs(q, n):
+    """config-3 robots, their oracle solution, and a 'previous tick' (slightly different commands) for warm starts"""
+    if n not in _cache:
+        from oracle import c_oracle as O
+        from quadruped_control_amd import workloads as W
+
+        P = q.cheetah_params(0.6)
+        b = W.config3(n, seed=0x5EED00A3)
+        ref, st, it = O.control_batch(P, b, threads=8)
+        assert (st == 0).all()
+        prev = dict(b)
+        prev["xdot_d"] = b["xdot_d"] * 0.9
+        prev["x"] = b["x"] + 1e-3
+        _cache[n] = (P, b, ref, prev)
+    return _cache[n]
+
+
+def _controller(q, P, form, tune):
+    ctl = q.BalanceController.from_params(P)
+    ctl.set_tuning(**FORMS[form])
+    ctl.set_tuning(**tune)
+    return ctl
+
+
+def _relerr(a, ref):
+    scale = np.maximum(1.0, np.abs(ref).max(axis=1, keepdims=True))
+    return float(np.max(np.abs(a - ref) / scale))
+
+
+_iters = {}
+
+
+@pytest.mark.parametrize("form,G,mode,tune,n", CASES, ids=IDS)
+@pytest.mark.parametrize("start", ["cold", "warm"])
+def test_kernel_instantiation_vs_oracle(q, form, G, mode, tune, n, start):
+    import torch
+
+    from tests.kkt_batch import assert_kkt
+
+    P, b, ref, prev = _inputs(q, n)
+    ctl = _controller(q, P, form, tune)
+    info = ctl.query_launch(n, warm=(start == "warm"))
+    assert (info["form"], info["lanes_per_robot"], info["mode"]) == (FORM_ID[form], G, mode), info
+    if mode == 0:
+        assert info["chunk"] > 64 // G  # persistent waves really refill
+    d = q.to_device(b)
+    warm = None
+    if start == "warm":
+        o0 = q.BalanceController.from_params(P).control_batch(q.to_device(prev), want_active_set=True)
+        warm = o0["active_set"]
+    o = ctl.control_batch(d, warm=warm, want_iterations=True, want_active_set=True)
+    torch.cuda.synchronize()
+    assert int((o["status"] != 0).sum()) == 0
+    grf = o["grf_body"].cpu().numpy()
+    assert _relerr(grf, ref) < RTOL
+    assert np.all(grf[np.repeat(b["stance"] == 0, 3, axis=1)] == 0.0)
+    assert_kkt(P, b, grf)
+    it = o["iterations"].cpu().numpy()
+    assert it.min() >= 1 and it.max() <= 200
+    if start == "cold":
+        _iters[(form, G, mode)] = it
+        first = next(iter(_iters.values()))
+        if first.shape == it.shape:  # same batch: every form walks the same working-set path
+            assert np.array_equal(first, it), (np.flatnonzero(first != it)[:10], IDS)
+    else:
+        cold = _iters.get((form, G, mode))
+        if cold is not None:
+            assert it.mean() < 0.8 * cold.mean(), (it.mean(), cold.mean())
+        # restarting from the optimal working set takes exactly one recalculation
+        again = ctl.control_batch(d, warm=o["active_set"], want_iterations=True)
+        torch.cuda.synchronize()
+        assert int(again["iterations"].max()) == 1
+        assert _relerr(again["grf_body"].cpu().numpy(), ref) < RTOL
+
+
+KIN_CASES = [c for c in CASES if not (c[0] != "dense" and c[1] == 1)] + [c for c in CASES if c[0] == "uniform" and c[1] == 1]
+
+
+@pytest.mark.parametrize("form,G,mode,tune,n", KIN_CASES, ids=[f"kin-{f}-G{g}-mode{m}" for f, g, m, _, _ in KIN_CASES])
+def test_kin_instantiation_vs_oracle(q, form, G, mode, tune, n):
+    """joint_q in / joint_tau out variants (KIN = true template instantiations) of the same branches."""
+    from oracle import c_oracle as O
+    from quadruped_control_amd import workloads as W
+
+    n = min(n, 8192) if not (form == "uniform" and G == 4 and mode == 1) else n
+    P = q.cheetah_params(0.6)
+    b = W.with_joint_angles(W.config3(n, seed=0x5EED00A4))
+    ctl = _controller(q, P, form, dict(tune, one_fill=0) if mode == 0 else tune)
+    info = ctl.query_launch(n, kin=True)
+    assert (info["form"], info["lanes_per_robot"], info["mode"]) == (FORM_ID[form], G, mode), info
+    o = ctl.control_batch_host(b, want_torques=True)
+    ref = O.tick_batch(P, b, threads=8)
+    assert (o["status"] == 0).all() and (ref["status"] == 0).all()
+    assert _relerr(o["grf_body"], ref["grf_body"]) < RTOL
+    assert np.max(np.abs(o["joint_tau"] - ref["joint_tau"])) < 1e-6 * 20.0
+
+
+def test_config5_shard_full_size(q):
+    """BASELINE.json configs[4]: one rank's shard of the 2,097,152-robot batch (rank 3 of 8: robots
+    [786432, 1048576), seed 0x5EED0005) at full size - every robot solved, feasible and KKT-certified, a
+    16,384-robot sample against the oracle, and shards generated independently tile the batch exactly."""
+    import torch
+
+    from tests.kkt_batch import assert_kkt
+    from oracle import c_oracle as O
+    from quadruped_control_amd import workloads as W
+    from quadruped_control_amd.sharding import shard_bounds
+
+    total, world, rank = 2097152, 8, 3
+    lo, hi = shard_bounds(total, rank, world)
+    assert (lo, hi) == (786432, 1048576)
+    P = q.cheetah_params(0.6)
+    b = W.config5(hi - lo, start=lo)
+    ctl = q.BalanceController.from_params(P)
+    o = ctl.control_batch(q.to_device(b), want_iterations=True)
+    torch.cuda.synchronize()
+    assert int((o["status"] != 0).sum()) == 0
+    grf = o["grf_body"].cpu().numpy()
+    assert_kkt(P, b, grf)
+    idx = np.random.default_rng(5).choice(hi - lo, 16384, replace=False)
+    sub = {k: np.ascontiguousarray(v[idx]) for k, v in b.items()}
+    ref, st, _ = O.control_batch(P, sub, threads=8)
+    assert (st == 0).all() and _relerr(grf[idx], ref) < RTOL
+    # the same robots as part of a differently cut batch (rank 1 of 4 owns [524288, 1048576)) give the same forces
+    lo4, hi4 = shard_bounds(total, 1, 4)
+    b4 = W.config5(hi4 - lo4, start=lo4)
+    o4 = ctl.control_batch(q.to_device(b4))
+    torch.cuda.synchronize()
+    g4 = o4["grf_body"].cpu().numpy()[lo - lo4:hi - lo4]
+    scale = np.maximum(1.0, np.abs(grf).max(axis=1, keepdims=True))
+    assert np.max(np.abs(g4 - grf) / scale) < 1e-8
+    hist = np.bincount(b["stance"].sum(axis=1), minlength=5)
+    assert hist[2] > 0 and hist[3] > 0 and hist[4] > 0  # mixed 2/3/4-foot contact states

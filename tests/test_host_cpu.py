@@ -20,7 +20,7 @@ def test_abi_exports_match_header(built):
     from quadruped_control_amd import _lib
 
     assert set(_lib.EXPORTS) == declared
-    assert _lib.load().qc_abi_version() == 3
+    assert _lib.load().qc_abi_version() == 4
 
 
 def test_param_struct_layout_matches_c():
@@ -30,6 +30,13 @@ def test_param_struct_layout_matches_c():
     assert ctypes.sizeof(_lib.QcBatchIn) == 18 * 8 and ctypes.sizeof(_lib.QcBatchOut) == 5 * 8
     assert ctypes.sizeof(_lib.QcKinematics) == 49 * 8
     assert ctypes.sizeof(_lib.QcSwingState) == 224
+    assert ctypes.sizeof(_lib.QcLaunchInfo) == 4 * 4 + 4 * 8
+
+
+def test_library_reads_no_environment():
+    """Stray QC_* variables must not alter the controller: every override goes through qc_set_tuning."""
+    src = open(os.path.join(ROOT, "quadruped_control_amd", "csrc", "qc_balance.hip")).read()
+    assert "getenv" not in src
 
 
 def test_no_gpu_fails_loudly(built):

@@ -3,7 +3,7 @@ import os, sys, subprocess, json
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 for cfg in (2, 3, 4):
     for g in (1, 2, 4):
-        env = dict(os.environ, QC_GROUP=str(g))
+        env = dict(os.environ)
         r = subprocess.run([sys.executable, "bench.py", "--no-cpu-baseline", "--no-sweep", "--config", str(cfg), "--steps", "50", "--warmup", "5"],
                            env=env, capture_output=True, text=True)
         try:
