@@ -653,6 +653,53 @@ QC_DEV double step_cand(bool free_face, double slack, double nd, int code) {
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
+// ------------------------------------------------------------ small SPD solve
+// M = L D L^T in place (packed lower triangle, index r (r + 1) / 2 + c: unit lower L below the diagonal, 1 / d_k on
+// it), then rhs <- M^-1 rhs.  No square roots: a pivot's reciprocal is v_rcp_f64 + two Newton steps, and the
+// triangular solves carry no scaling on their serial chain.  Returns false if a pivot is not positive (M not PD).
+template <int N>
+QC_DEV bool ldlt_solve(double (&M)[N * (N + 1) / 2], double (&x)[N]) {
+#define QC_LI(r, c) ((r) * ((r) + 1) / 2 + (c))
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    double d = M[QC_LI(k, k)];
+#pragma unroll
+    for (int m = 0; m < k; m++) {
+      const double u = M[QC_LI(k, m)];        // still unscaled: u_km = L_km d_m
+      M[QC_LI(k, m)] = u * M[QC_LI(m, m)];    // L_km
+      d = __builtin_fma(-M[QC_LI(k, m)], u, d);
+    }
+    ok = ok && (d > 0.0);
+    M[QC_LI(k, k)] = rcp_nr(d);
+#pragma unroll
+    for (int r = k + 1; r < N; r++) {  // u_rk = M_rk - sum_m u_rm L_km (scaled when row r becomes the pivot row)
+      double t = M[QC_LI(r, k)];
+#pragma unroll
+      for (int m = 0; m < k; m++) t = __builtin_fma(-M[QC_LI(r, m)], M[QC_LI(k, m)], t);
+      M[QC_LI(r, k)] = t;
+    }
+  }
+#pragma unroll
+  for (int k = 1; k < N; k++) {
+    double t = x[k];
+#pragma unroll
+    for (int m = 0; m < k; m++) t = __builtin_fma(-M[QC_LI(k, m)], x[m], t);
+    x[k] = t;
+  }
+#pragma unroll
+  for (int k = 0; k < N; k++) x[k] *= M[QC_LI(k, k)];
+#pragma unroll
+  for (int k = N - 2; k >= 0; k--) {
+    double t = x[k];
+#pragma unroll
+    for (int m = k + 1; m < N; m++) t = __builtin_fma(-M[QC_LI(m, k)], x[m], t);
+    x[k] = t;
+  }
+#undef QC_LI
+  return ok;
+}
+
 // -------------------------------------------------------------- EQP, diagonal W
 // Equality-constrained subproblem on the current face, 6-dimensional form.
 // With f = T y + p (T,p from the cube states), diagonal W and u = A f - b:
@@ -1021,38 +1068,7 @@ struct EqpDense {
       y[3 * i + 1] = -ay[i] * gp[3 * i + 1];
       y[3 * i + 2] = -(cx[i] * gp[3 * i] + cy[i] * gp[3 * i + 1] + az[i] * gp[3 * i + 2]);
     }
-    // Cholesky H = L L^T, in place, inverse diagonal
-    bool ok = true;
-#pragma unroll
-    for (int k = 0; k < 12; k++) {
-      double d = L[QC_SYM(k, k)];
-#pragma unroll
-      for (int m = 0; m < k; m++) d = __builtin_fma(-L[QC_SYM(k, m)], L[QC_SYM(k, m)], d);
-      ok = ok && (d > 0.0);
-      const double rinv = rsqrt_nr(d);
-      L[QC_SYM(k, k)] = rinv;
-#pragma unroll
-      for (int r = k + 1; r < 12; r++) {
-        double t = L[QC_SYM(r, k)];
-#pragma unroll
-        for (int m = 0; m < k; m++) t = __builtin_fma(-L[QC_SYM(r, m)], L[QC_SYM(k, m)], t);
-        L[QC_SYM(r, k)] = t * rinv;
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < 12; k++) {
-      double t = y[k];
-#pragma unroll
-      for (int m = 0; m < k; m++) t = __builtin_fma(-L[QC_SYM(k, m)], y[m], t);
-      y[k] = t * L[QC_SYM(k, k)];
-    }
-#pragma unroll
-    for (int k = 11; k >= 0; k--) {
-      double t = y[k];
-#pragma unroll
-      for (int m = k + 1; m < 12; m++) t = __builtin_fma(-L[QC_SYM(m, k)], y[m], t);
-      y[k] = t * L[QC_SYM(k, k)];
-    }
+    const bool ok = ldlt_solve<12>(L, y);  // H = L D L^T, y <- H^-1 rhs
     // f = T y + p
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -1072,6 +1088,176 @@ struct EqpDense {
         g[r] = __builtin_fma(v, f[cc], g[r]);
         if (r != cc) g[cc] = __builtin_fma(v, f[r], g[cc]);
       }
+    return ok;
+  }
+};
+
+
+// The dense form on four lanes per robot (stride-16 layout, lane m = foot m): the latency variant for batches
+// that cannot fill the chip, where the slowest robot's serial chain of recalculations is what is timed.
+// Split of one recalculation:
+//   distributed   block row m of the reduced Hessian H = T^T Q T (3 x 12, from the lane's three rows of Q, which
+//                 stay in registers for the robot's lifetime), its part of the right-hand side, the foot's force,
+//                 gradient, ratio test and multipliers (Lane::iterate, shared with the 6x6 kernels)
+//   exchanged     the 144 + 12 doubles of H and the right-hand side, through a per-robot LDS tile
+//                 (entry e of robot g at X[e * 17 + g]: the 16 lanes of one foot write consecutive words, the
+//                 four lanes of a robot read the same word - no bank conflicts either way)
+//   replicated    the 12 x 12 LDL^T and the two triangular solves (a distributed factorisation would pay one
+//                 cross-lane transfer per factor entry, which costs as much as the flops it saves)
+// The exchange is wave-synchronous (the four lanes of a robot sit in one wavefront): no barrier, only the
+// wave-level fence that keeps the compiler from moving LDS reads across the writes of other lanes.
+struct EqpDense4 {
+  static constexpr int G = 4;
+  static constexpr bool kStrided = true;
+  static constexpr bool kUniform = false;
+  static constexpr bool kRepackTail = false;
+  static constexpr int XS = 17;           // tile stride in doubles (16 robots + 1)
+  static constexpr int X_DOUBLES = 156 * XS;
+  double* X;        // this robot's column of the wave's exchange tile
+  double Qr[3][12]; // rows 3 me .. 3 me + 2 of Q = 2 (A^T S A + W), BC.cpp:152
+  double c[3];      // entries of c = -2 A^T S b, BC.cpp:153
+  int me;
+
+  QC_DEV explicit EqpDense4(double* lds_lane) {
+    const int lane = (int)threadIdx.x;
+    X = (lds_lane - lane) + (lane & 15);
+    me = lane >> 4;
+  }
+  static QC_DEV void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+
+  // assemble this lane's three rows of Q and of c for the robot the group just fetched
+  QC_DEV void setup(CParams& P, const Wrench<1>& Wr, int) {
+    double r[4][3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) X[(3 * me + k) * XS] = Wr.r[0][k];
+    wave_sync();
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int k = 0; k < 3; k++) r[j][k] = X[(3 * j + k) * XS];
+    wave_sync();  // the tile is rewritten by the first recalculation
+    const double ix = Wr.r[0][0], iy = Wr.r[0][1], iz = Wr.r[0][2];
+    double Sb[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      double t = 0.0;
+#pragma unroll
+      for (int m = 0; m < 6; m++) t = __builtin_fma(P.S[6 * k + m], Wr.b[m], t);
+      Sb[k] = t;
+    }
+    c[0] = -2.0 * (Sb[0] + Sb[4] * iz - Sb[5] * iy);
+    c[1] = -2.0 * (Sb[1] - Sb[3] * iz + Sb[5] * ix);
+    c[2] = -2.0 * (Sb[2] + Sb[3] * iy - Sb[4] * ix);
+    const double* Wg = (const double*)(unsigned long long)(&P.W[0]) + 36 * me;  // rows 3 me ... of W: a per-lane (vector) load
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const double rx = r[j][0], ry = r[j][1], rz = r[j][2];
+#pragma unroll
+      for (int b = 0; b < 3; b++) {
+        double SA[6];  // column b of S [I; [r_j]x]
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+          if (b == 0) SA[k] = P.S[6 * k + 0] + P.S[6 * k + 4] * rz - P.S[6 * k + 5] * ry;
+          if (b == 1) SA[k] = P.S[6 * k + 1] - P.S[6 * k + 3] * rz + P.S[6 * k + 5] * rx;
+          if (b == 2) SA[k] = P.S[6 * k + 2] + P.S[6 * k + 3] * ry - P.S[6 * k + 4] * rx;
+        }
+        // column b of A_me^T S A_j
+        const double t0 = SA[0] + SA[4] * iz - SA[5] * iy;
+        const double t1 = SA[1] - SA[3] * iz + SA[5] * ix;
+        const double t2 = SA[2] + SA[3] * iy - SA[4] * ix;
+        Qr[0][3 * j + b] = 2.0 * (t0 + Wg[0 * 12 + 3 * j + b]);
+        Qr[1][3 * j + b] = 2.0 * (t1 + Wg[1 * 12 + 3 * j + b]);
+        Qr[2][3 * j + b] = 2.0 * (t2 + Wg[2 * 12 + 3 * j + b]);
+      }
+    }
+  }
+
+  QC_DEV bool solve(CParams& P, const Wrench<1>&, const Cube<1>& C, uint32_t stance, int, double (&f)[3], double (&g)[3]) {
+    // working set of the whole robot: every lane contributes its foot's six bits
+    const uint32_t word = (uint32_t)group_or<4, true>((int)(encode_foot(C.sx[0], C.sy[0], C.sz[0]) << (6 * me)));
+    double ax[4], ay[4], az[4], cx[4], cy[4], mx[4], my[4], fzfix[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const bool st = (stance >> j) & 1u;
+      const int sx = dec2(word >> (6 * j)), sy = dec2(word >> (6 * j + 2)), sz = dec2(word >> (6 * j + 4));
+      ax[j] = (st && sx == 0) ? 1.0 : 0.0;
+      ay[j] = (st && sy == 0) ? 1.0 : 0.0;
+      az[j] = (st && sz == 0) ? 1.0 : 0.0;
+      mx[j] = P.mu * (double)sx;
+      my[j] = P.mu * (double)sy;
+      cx[j] = mx[j] * az[j];
+      cy[j] = my[j] * az[j];
+      fzfix[j] = st ? (sz > 0 ? P.fzmax : (sz < 0 ? P.fzmin : 0.0)) : 0.0;
+    }
+    // this lane's own coefficients (its foot's state is in C)
+    const bool sti = (stance >> me) & 1u;
+    const double axi = (sti && C.sx[0] == 0) ? 1.0 : 0.0, ayi = (sti && C.sy[0] == 0) ? 1.0 : 0.0, azi = (sti && C.sz[0] == 0) ? 1.0 : 0.0;
+    const double mxi = P.mu * (double)C.sx[0], myi = P.mu * (double)C.sy[0];
+    const double cxi = mxi * azi, cyi = myi * azi;
+    const double fzfi = sti ? (C.sz[0] > 0 ? P.fzmax : (C.sz[0] < 0 ? P.fzmin : 0.0)) : 0.0;
+    // block row me of H = T^T Q T + (I - D) and of gp = Q p + c
+    double gp[3] = {c[0], c[1], c[2]};
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const double onj = (j == me) ? 1.0 : 0.0;  // the identity of the fixed slots sits on the diagonal block
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        const double t = Qr[a][3 * j] * mx[j] + Qr[a][3 * j + 1] * my[j] + Qr[a][3 * j + 2];
+        gp[a] = __builtin_fma(fzfix[j], t, gp[a]);
+      }
+      double Xb[3][3];  // Q_(me,j) T_j
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        Xb[a][0] = Qr[a][3 * j] * ax[j];
+        Xb[a][1] = Qr[a][3 * j + 1] * ay[j];
+        Xb[a][2] = Qr[a][3 * j] * cx[j] + Qr[a][3 * j + 1] * cy[j] + Qr[a][3 * j + 2] * az[j];
+      }
+#pragma unroll
+      for (int b = 0; b < 3; b++) {
+        double h0 = axi * Xb[0][b];
+        double h1 = ayi * Xb[1][b];
+        double h2 = cxi * Xb[0][b] + cyi * Xb[1][b] + azi * Xb[2][b];
+        if (b == 0) h0 += onj * (1.0 - axi);
+        if (b == 1) h1 += onj * (1.0 - ayi);
+        if (b == 2) h2 += onj * (1.0 - azi);
+        X[(12 * (3 * me + 0) + 3 * j + b) * XS] = h0;
+        X[(12 * (3 * me + 1) + 3 * j + b) * XS] = h1;
+        X[(12 * (3 * me + 2) + 3 * j + b) * XS] = h2;
+      }
+    }
+    X[(144 + 3 * me + 0) * XS] = -axi * gp[0];
+    X[(144 + 3 * me + 1) * XS] = -ayi * gp[1];
+    X[(144 + 3 * me + 2) * XS] = -(cxi * gp[0] + cyi * gp[1] + azi * gp[2]);
+    wave_sync();
+    double L[78], y[12];
+#pragma unroll
+    for (int r = 0; r < 12; r++)
+#pragma unroll
+      for (int cc = 0; cc <= r; cc++) L[r * (r + 1) / 2 + cc] = X[(12 * r + cc) * XS];
+#pragma unroll
+    for (int k = 0; k < 12; k++) y[k] = X[(144 + k) * XS];
+    wave_sync();  // the next recalculation (or the next robot's setup) rewrites the tile
+    const bool ok = ldlt_solve<12>(L, y);
+    // forces of all feet (f = T y + p), then this foot's rows of g = Q f + c
+    g[0] = c[0]; g[1] = c[1]; g[2] = c[2];
+    double fo[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const double fz = __builtin_fma(az[j], y[3 * j + 2], fzfix[j]);
+      const double fx = __builtin_fma(ax[j], y[3 * j], mx[j] * fz);
+      const double fy = __builtin_fma(ay[j], y[3 * j + 1], my[j] * fz);
+#pragma unroll
+      for (int a = 0; a < 3; a++) g[a] = __builtin_fma(Qr[a][3 * j], fx, __builtin_fma(Qr[a][3 * j + 1], fy, __builtin_fma(Qr[a][3 * j + 2], fz, g[a])));
+      const bool own = j == me;
+      fo[0] = own ? fx : fo[0];
+      fo[1] = own ? fy : fo[1];
+      fo[2] = own ? fz : fo[2];
+    }
+    f[0] = fo[0]; f[1] = fo[1]; f[2] = fo[2];
     return ok;
   }
 };

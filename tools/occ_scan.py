@@ -4,7 +4,7 @@ min_waves > 2 rows.  usage: python tools/occ_scan.py [lib] ; prints one line per
 import os, sys, json
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 from quadruped_control_amd import _lib
-if len(sys.argv) > 1:
+if len(sys.argv) > 1 and not sys.argv[1].startswith("--"):
     _lib.LIB_PATH = os.path.abspath(sys.argv[1])
 import numpy as np, torch
 import quadruped_control_amd as q
@@ -27,7 +27,7 @@ def timeit(ctl, b, warm, reps=20):
     return e0.elapsed_time(e1) / reps * 1e3, out
 
 
-VARIANTS = [dict(), dict(group=2, one_fill=1), dict(group=2, one_fill=1, min_waves=3), dict(group=2, one_fill=1, min_waves=4),
+VARIANTS = [dict(), dict(group=2, one_fill=1, multi_fill=0), dict(group=2, one_fill=1, multi_fill=1), dict(group=2, one_fill=1, min_waves=3), dict(group=2, one_fill=1, min_waves=4),
             dict(group=4, one_fill=1), dict(group=4, one_fill=1, min_waves=3), dict(group=4, one_fill=1, min_waves=4),
             dict(group=2, one_fill=0), dict(group=4, one_fill=0), dict(group=1)]
 work = []
