@@ -203,6 +203,18 @@ def cpu_baseline(P, batch, budget_s=4.0):
         if time.perf_counter() - t0 >= budget_s:
             break
     dt = time.perf_counter() - t0
+    literal = None
+    try:  # the literal reference sequence (qpOASES init -> hotstart), only where qpOASES itself is installed
+        from oracle.qpoases_ref import run as qref
+
+        if qref.find_qpoases() is not None and qref.build() is not None:
+            literal = json.loads(subprocess.run([sys.executable, qref.__file__, "time", "4096"], capture_output=True, text=True,
+                                                timeout=300).stdout.strip().splitlines()[-1])
+    except Exception:
+        literal = None
+    if literal is not None and literal.get("kind") == "reference":
+        literal["port_value"] = reps * n / dt
+        return literal
     return {"value": reps * n / dt, "unit": "QPs/s", "cores": threads, "kind": "port",
             "sample": f"first {base} robots of the benchmark batch tiled x{tile} = {n} robots per call x {reps} calls, {threads} OpenMP threads, "
                       f"{dt:.1f} s wall; C restatement (textbook primal active set), not qpOASES",

@@ -211,6 +211,11 @@ public:
       feet[3 * i] = p(0); feet[3 * i + 1] = p(1); feet[3 * i + 2] = p(2);
       stance_flags[i] = gait_map.at(leg_names_.at(i)).first == LegState::stance ? 1 : 0;
     }
+    // Armadillo throws a size-mismatch std::logic_error when the reference multiplies wrongly sized arguments
+    // (balance_controller.cpp:126-139); the same misuse must not run past the fixed-size records here.
+    if (Rwb.n_rows != 3 || Rwb.n_cols != 3 || Rwb_d.n_rows != 3 || Rwb_d.n_cols != 3 || x.size() != 3 || xdot.size() != 3 ||
+        w.size() != 3 || x_d.size() != 3 || xdot_d.size() != 3 || w_d.size() != 3)
+      throw std::logic_error("BalanceController::control: rotations must be 3x3 and vectors of size 3");
     copy_to_real_t(Rwb, a_Rwb);
     copy_to_real_t(Rwb_d, a_Rwbd);
     copy_to_real_t(x, a_x);

@@ -9,7 +9,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "liboracle.so")
+_SO = os.environ.get("QC_ORACLE_SO") or os.path.join(_HERE, "liboracle.so")  # QC_ORACLE_SO: sanitizer build (make -C oracle sanitize)
 
 
 class OracleParams(C.Structure):

@@ -47,7 +47,7 @@ namespace qc {
 enum { IN_B = 0, IN_R = 6, IN_FLAGS = 18, IN_IDX = 19, IN_PLANES = 20,
        OUT_F = 0, OUT_STAT = 12, OUT_WORD = 13, OUT_IDX = 14, OUT_PLANES = 15,
        STOCK_PLANES = IN_PLANES + OUT_PLANES };
-constexpr int stock_slots(int G, int MODE) { return (MODE == 0 || MODE == 3) ? 64 : 64 / G; }
+constexpr int stock_slots(int G, int MODE) { return MODE == 0 ? 64 : 64 / G; }
 constexpr int stock_doubles(int slots) { return ((STOCK_PLANES * (slots + 1) + 63) / 64) * 64; }
 
 template <class Eqp, bool KIN>
@@ -474,27 +474,19 @@ QC_DEV void flush_out(const DevParams* __restrict__ Pg, const BatchIn& in, const
 // whose recalculation is 30 % shorter (620 vs 894 instructions) - and the wave waits for exactly these stragglers.
 // The running robots are re-packed through the (now idle) input stock and finish on the G = 4 body; `slot` is
 // where the robot's result goes in the output stock.  `bm` = ballot(busy), popcount <= 32.
-// Where the re-pack records live.  One-fill stock (32 slots, idle once the wave has loaded its robots): contiguous
-// records of RS doubles.  64-slot stock of the multi-fill mode: the later sub-fills are still waiting in it, so the
-// records go into the 32 slots the CURRENT sub-fill has just consumed - field f of record r at plane f % 20, slot
-// base + 2 r + f / 20 (two slots per record, 16 records).
-template <int SP, bool MULTI>
-QC_DEV int repack_at(int rank, int f, int base_slot) {
-  return MULTI ? (f % IN_PLANES) * SP + base_slot + 2 * rank + f / IN_PLANES : rank * 37 + f;
-}
-template <bool KIN, bool UNIFORM, int SP, bool MULTI, class Lane2>
-QC_DEV void finish_on_four_lanes(const DevParams* __restrict__ Pg, const Lane2& L, bool busy, unsigned long long bm, int slot, int base_slot, int member,
-                                 int lane, double* __restrict__ sin, double* __restrict__ sout) {
+template <bool KIN, bool UNIFORM, int SP, class Lane2>
+QC_DEV void finish_on_four_lanes(const DevParams* __restrict__ Pg, const Lane2& L, bool busy, unsigned long long bm, int slot, int member, int lane,
+                                 double* __restrict__ sin, double* __restrict__ sout) {
   using Eqp4 = EqpDiagW<UNIFORM, 4, !QC_NO_STRIDED>;
   using Lane4 = Lane<Eqp4, KIN>;
   constexpr bool STR4 = Eqp4::kStrided;
   const int nb = __builtin_popcountll(bm) / 2;  // running robots
   if (nb == 0) return;
-  constexpr int RS = 37;  // fields per record (odd stride in the one-fill stock: the four lanes of a group read different banks)
-  static_assert(MULTI ? RS <= 2 * IN_PLANES : 16 * RS <= IN_PLANES * SP, "the re-pack records live in consumed slots of the input stock");
+  constexpr int RS = 37;  // record stride in doubles (odd: the four lanes of a group read different banks)
+  static_assert(16 * RS <= IN_PLANES * SP, "the re-pack records live in the idle input stock");
   const int rank2 = __builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0)) / 2;
   __syncthreads();  // nobody reads the input stock any more
-#define QC_REC(rank, f) sin[repack_at<SP, MULTI>((rank), (f), base_slot)]
+#define QC_REC(rank, f) sin[(rank) * RS + (f)]
   if (busy) {
     if (member == 0) {
 #pragma unroll
@@ -554,8 +546,6 @@ QC_DEV void finish_on_four_lanes(const DevParams* __restrict__ Pg, const Lane2& 
 
 // MODE 0: persistent waves (chunks of many fills, lane refill).  MODE 1: the launch gives every wave at most one
 // fill (chunk <= 64 / G).  MODE 2: one fill and the SIMD to itself, recalculation constants resident in VGPRs.
-// MODE 3: 64 robots per wave, assembled densely in one restock and solved 64 / G at a time with the lean
-// one-fill bodies (batches of many rounds of workgroups, where assembly instructions are what is left to save).
 template <class Eqp, bool KIN, int MIN_WAVES_PER_SIMD, int MODE = 0>
 __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const DevParams* __restrict__ Pg, const long n, const BatchIn in,
                                                                          const uint32_t* __restrict__ warm, const BatchOut out, const long chunk,
@@ -584,8 +574,6 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
     // recalculation) is dead weight on the serial chain that bounds such a batch.  One fill, a divergent solve
     // loop, one push, one flush.
     constexpr bool RESIDENT = MODE == 2;
-    constexpr bool MULTI = MODE == 3;
-    static_assert(!(MULTI && STR), "the multi-fill mode is built for the adjacent-lane kernels");
     if (cursor >= end) return;
     UConst uc;  // RESIDENT: the recalculation's constants live in VGPRs (no scalar load + wait per recalculation)
     if constexpr (RESIDENT) uc = load_uconst(*QC_PARAMS_HERE(Pg));
@@ -629,47 +617,39 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
       flush_out<Eqp::G, KIN, STR, SP>(Pg, in, out, sout, stock_n, lane);
       return;
     }
-    // MULTI (MODE 3): the restock above assembled up to 64 robots densely (one per lane: half the assembly
-    // instructions per robot of a 32-robot fill at G = 2); the wave now solves them 64 / G at a time.
-    constexpr int RPW = 64 / G;
-    const int nsub = MULTI ? (stock_n + RPW - 1) / RPW : 1;
-    for (int sub = 0; sub < nsub; sub++) {
-      const int base_slot = sub * RPW, slot = base_slot + grp;
-      busy = slot < stock_n;
-      if (busy) {
-        L.template load_from_stock<SP>(sin, slot, member);
-        eqp.setup(*QC_PARAMS_HERE(Pg), L.Wr, L.foot0);
+    if (busy) {
+      L.template load_from_stock<SP>(sin, grp, member);
+      eqp.setup(*QC_PARAMS_HERE(Pg), L.Wr, L.foot0);
+    }
+    const bool mine = busy;
+    busy = busy && !probe;
+    QC_CLK(0, 2);
+    if (busy) {  // every robot of a one-fill wave is fresh exactly once: the clamp step is peeled
+      if constexpr (RESIDENT) {
+        pin_uconst(uc);
+        busy = !L.template iterate<LaneT::FIRST>(uc, eqp);
+      } else {
+        busy = !L.template iterate<LaneT::FIRST>(*QC_PARAMS_HERE(Pg), eqp);
       }
-      const bool mine = busy;
-      busy = busy && !probe;
-      QC_CLK(0, 2);
-      if (busy) {  // every robot of a one-fill wave is fresh exactly once: the clamp step is peeled
+    }
+    if constexpr (Eqp::kRepackTail) {
+      unsigned long long bm = __builtin_amdgcn_ballot_w64(busy);
+      while (__builtin_popcountll(bm) > 32) {
+        if (busy) busy = !L.template iterate<LaneT::STEADY>(*QC_PARAMS_HERE(Pg), eqp);
+        bm = __builtin_amdgcn_ballot_w64(busy);
+      }
+      if (!busy && mine) L.template push_result<SP>(sout, grp);  // finished in the two-lane layout
+      finish_on_four_lanes<KIN, Eqp::kUniform, SP>(Pg, L, busy, bm, grp, member, lane, sin, sout);
+    } else {
+      while (busy) {
         if constexpr (RESIDENT) {
           pin_uconst(uc);
-          busy = !L.template iterate<LaneT::FIRST>(uc, eqp);
+          busy = !L.template iterate<LaneT::STEADY>(uc, eqp);
         } else {
-          busy = !L.template iterate<LaneT::FIRST>(*QC_PARAMS_HERE(Pg), eqp);
+          busy = !L.template iterate<LaneT::STEADY>(*QC_PARAMS_HERE(Pg), eqp);
         }
       }
-      if constexpr (Eqp::kRepackTail) {
-        unsigned long long bm = __builtin_amdgcn_ballot_w64(busy);
-        while (__builtin_popcountll(bm) > 32) {
-          if (busy) busy = !L.template iterate<LaneT::STEADY>(*QC_PARAMS_HERE(Pg), eqp);
-          bm = __builtin_amdgcn_ballot_w64(busy);
-        }
-        if (!busy && mine) L.template push_result<SP>(sout, slot);  // finished in the two-lane layout
-        finish_on_four_lanes<KIN, Eqp::kUniform, SP, MULTI>(Pg, L, busy, bm, slot, base_slot, member, lane, sin, sout);
-      } else {
-        while (busy) {
-          if constexpr (RESIDENT) {
-            pin_uconst(uc);
-            busy = !L.template iterate<LaneT::STEADY>(uc, eqp);
-          } else {
-            busy = !L.template iterate<LaneT::STEADY>(*QC_PARAMS_HERE(Pg), eqp);
-          }
-        }
-        if (mine) L.template push_result<SP>(sout, slot);
-      }
+      if (mine) L.template push_result<SP>(sout, grp);
     }
     QC_CLK(7, 8);
     __syncthreads();
@@ -761,8 +741,6 @@ struct qc_handle {
   int group_override;      // 1, 2, 4: lanes per robot
   int one_fill_override;   // 0: never (persistent waves), 1: always, -1: heuristic
   int wave_slots_override; // > 0: resident workgroups assumed for every kernel instead of the occupancy query
-  int multi_fill_override; // -1 heuristic, 0 never, 1 always: 64-robot multi-fill workgroups (mode 3)
-  double multi_rounds;     // mode 3 from this many rounds of one-fill workgroups on
   int min_waves;           // development builds (QC_EXPERIMENTAL_OCC): register cap of the one-fill kernels, waves per SIMD
   // resident workgroups per kernel instantiation (hipOccupancyMaxActiveBlocksPerMultiprocessor x CUs), filled lazily
   struct { qc_kernel_fn fn; size_t lds; long resident; } occ[40];
@@ -868,9 +846,6 @@ enum { QC_FORM_UNIFORM = 0, QC_FORM_GENERAL = 1, QC_FORM_DENSE = 2 };
 #ifndef QC_ROUNDS_COLD
 #define QC_ROUNDS_COLD 1.0
 #endif
-#ifndef QC_MULTI_ROUNDS
-#define QC_MULTI_ROUNDS 3.0
-#endif
 #ifndef QC_ROUNDS_WARM
 #define QC_ROUNDS_WARM 6.0
 #endif
@@ -879,8 +854,7 @@ template <class EQP, int MINW, int MODE>
 static qc_kernel_fn kernel_of(bool kin) {
   return kin ? (qc_kernel_fn)qc::balance_kernel<EQP, true, MINW, MODE> : (qc_kernel_fn)qc::balance_kernel<EQP, false, MINW, MODE>;
 }
-// the kernel instantiation for (form, lanes per robot, mode); mode 2 exists for the uniform G = 4 form only,
-// mode 3 for the two-lane kernels of the 6x6 forms
+// the kernel instantiation for (form, lanes per robot, mode); mode 2 exists for the uniform G = 4 form only
 static qc_kernel_fn kernel_for(int form, int G, int mode, bool kin, int minw = 2) {
   using namespace qc;
   constexpr bool STR = !QC_NO_STRIDED;
@@ -894,11 +868,11 @@ static qc_kernel_fn kernel_for(int form, int G, int mode, bool kin, int minw = 2
   if (form == QC_FORM_DENSE) return G == 4 ? kernel_of<EqpDense4, 1, 1>(kin) : (mode ? kernel_of<EqpDense, 1, 1>(kin) : kernel_of<EqpDense, 1, 0>(kin));
   if (form == QC_FORM_GENERAL) {
     if (G == 4) return mode ? kernel_of<EqpDiagW<false, 4, STR>, 2, 1>(kin) : kernel_of<EqpDiagW<false, 4>, 2, 0>(kin);
-    if (G == 2) return mode == 3 ? kernel_of<EqpDiagW<false, 2>, 2, 3>(kin) : (mode ? kernel_of<EqpDiagW<false, 2>, 2, 1>(kin) : kernel_of<EqpDiagW<false, 2>, 2, 0>(kin));
+    if (G == 2) return mode ? kernel_of<EqpDiagW<false, 2>, 2, 1>(kin) : kernel_of<EqpDiagW<false, 2>, 2, 0>(kin);
     return kernel_of<EqpDiagW<false, 1>, 2, 0>(kin);
   }
   if (G == 4) return mode == 2 ? kernel_of<EqpDiagW<true, 4, STR>, 2, 2>(kin) : (mode ? kernel_of<EqpDiagW<true, 4, STR>, 2, 1>(kin) : kernel_of<EqpDiagW<true, 4>, 2, 0>(kin));
-  if (G == 2) return mode == 3 ? kernel_of<EqpDiagW<true, 2>, 2, 3>(kin) : (mode ? kernel_of<EqpDiagW<true, 2>, 2, 1>(kin) : kernel_of<EqpDiagW<true, 2>, 2, 0>(kin));
+  if (G == 2) return mode ? kernel_of<EqpDiagW<true, 2>, 2, 1>(kin) : kernel_of<EqpDiagW<true, 2>, 2, 0>(kin);
   return kernel_of<EqpDiagW<true, 1>, 2, 0>(kin);
 }
 static size_t lds_for(int form, int G, int mode) {
@@ -968,11 +942,6 @@ static int plan_launch(qc_handle* h, long n, bool kin, bool warm, qc_launch_plan
     const long blocks = (n + chunk - 1) / chunk;
     // one wave per SIMD is enough: the recalculation's constants stay resident in VGPRs (uniform G = 4 form)
     mode = (form == QC_FORM_UNIFORM && G == 4 && blocks <= (long)h->cus * 4) ? 2 : 1;
-    // Many rounds of one-fill workgroups (a warm-started 262 144-robot tick is four): 64 robots per wave, assembled
-    // densely - one robot per lane instead of one per lane pair - and solved in two sub-fills.
-    bool multi = form != QC_FORM_DENSE && G == 2 && h->chunk_override <= 0 && (double)blocks >= h->multi_rounds * (double)resident;
-    if (h->multi_fill_override >= 0) multi = h->multi_fill_override != 0 && form != QC_FORM_DENSE && G == 2;
-    if (multi) { mode = 3; chunk = 64; }
   } else {
     resident = resident_workgroups(h, kernel_for(form, G, 0, kin), lds_for(form, G, 0));
     chunk = rpw;
@@ -1157,8 +1126,6 @@ int qc_create(const qc_params* p, int device, qc_handle** out) {
   h->one_fill_override = -1;
   h->wave_slots_override = 0;
   h->min_waves = 2;
-  h->multi_fill_override = -1;
-  h->multi_rounds = QC_MULTI_ROUNDS;
   h->n_occ = 0;
   if (hipSetDevice(device) != hipSuccess || hipMalloc((void**)&h->d_params, sizeof(qc::DevParams)) != hipSuccess ||
       hipMemcpy(h->d_params, &h->dp, sizeof(qc::DevParams), hipMemcpyHostToDevice) != hipSuccess) {
@@ -1180,8 +1147,6 @@ int qc_set_tuning(qc_handle* h, const char* key, double value) {
   } else if (k == "one_fill") h->one_fill_override = value < 0 ? -1 : (value != 0 ? 1 : 0);
   else if (k == "chunk") h->chunk_override = value > 0 ? (long)value : 0;
   else if (k == "wave_slots") h->wave_slots_override = value > 0 ? (int)value : 0;
-  else if (k == "multi_fill") h->multi_fill_override = value < 0 ? -1 : (value != 0 ? 1 : 0);
-  else if (k == "multi_rounds") h->multi_rounds = value;
   else if (k == "min_waves") h->min_waves = value > 2 ? (int)value : 2;
   else if (k == "refill_t") h->refill_t = value > 0 ? (int)value : 16;
   else if (k == "rounds_cold") h->rounds_cold = value;

@@ -17,5 +17,5 @@ def built():
     """Make sure the in-tree native artefacts exist (no-op when prebuilt)."""
     import __graft_entry__ as g
 
-    g.build()
+    g.build(force=False)
     return g

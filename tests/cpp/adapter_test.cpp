@@ -54,6 +54,13 @@ int main()
   try { balance_controller.control(Rwb, Rwb_d, x, zero, zero, x, zero, zero, bad); std::printf("FAIL out_of_range\n"); fails++; }
   catch (const std::out_of_range&) { std::printf("OK out_of_range\n"); }
 
+  // wrongly sized arguments: an exception (Armadillo's size-mismatch logic_error in the reference), never an overrun
+  const vec six = { 0.0, 0.0, 0.26, 0.0, 0.0, 0.0 };
+  try { balance_controller.control(Rwb, Rwb_d, six, zero, zero, x, zero, zero, feet); std::printf("FAIL size_check\n"); fails++; }
+  catch (const std::logic_error&) { std::printf("OK size_check\n"); }
+  try { balance_controller.control(eye(4, 4), Rwb_d, x, zero, zero, x, zero, zero, feet); std::printf("FAIL size_check_mat\n"); fails++; }
+  catch (const std::logic_error&) { std::printf("OK size_check_mat\n"); }
+
   // row-major helper (balance_controller.cpp:30-41)
   mat m = { { 1.0, 2.0 }, { 3.0, 4.0 } };
   real_t arr[4];

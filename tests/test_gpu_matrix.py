@@ -2,7 +2,7 @@
 
 The planner (plan_launch, qc_balance.hip) chooses by formulation (uniform 6x6 / general 6x6 / dense 12x12),
 lanes per robot (1 / 2 / 4) and kernel mode (0 persistent waves with lane refill, 1 one fill per wave, 2 one fill
-with register-resident constants, 3 dense 64-robot assembly + sub-fills).  Each test forces one branch with qc_set_tuning, checks through qc_query_launch
+with register-resident constants).  Each test forces one branch with qc_set_tuning, checks through qc_query_launch
 that this branch is the one that runs, and compares with the C oracle on config-3 inputs (mixed 2/3/4-foot contact
 states), cold and warm-started; the joint_q / joint_tau (KIN) instantiations run the fused tick against the oracle's
 composition.  Cold runs of all forms must also take the same working-set path (identical iteration counts).
@@ -21,8 +21,7 @@ CASES = []
 for form in ("uniform", "general"):
     CASES += [(form, 1, 0, dict(group=1, chunk=256), 8192),
               (form, 2, 0, dict(group=2, chunk=256), 8192),
-              (form, 2, 1, dict(group=2, one_fill=1, multi_fill=0), 8192),
-              (form, 2, 3, dict(group=2, one_fill=1, multi_fill=1), 8200),  # ragged: the last wave holds 8 robots
+              (form, 2, 1, dict(group=2, one_fill=1), 8200),  # ragged: the last wave holds 8 robots
               (form, 4, 0, dict(group=4, chunk=128), 8192),
               (form, 4, 1, dict(group=4, one_fill=1), 20480 if form == "uniform" else 8192)]
 CASES += [("uniform", 4, 2, dict(group=4, one_fill=1), 8192),
@@ -87,8 +86,6 @@ def test_kernel_instantiation_vs_oracle(q, form, G, mode, tune, n, start):
     assert (info["form"], info["lanes_per_robot"], info["mode"]) == (FORM_ID[form], G, mode), info
     if mode == 0:
         assert info["chunk"] > 64 // G  # persistent waves really refill
-    if mode == 3:
-        assert info["chunk"] == 64
     d = q.to_device(b)
     warm = None
     if start == "warm":
