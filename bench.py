@@ -284,7 +284,7 @@ def host_boundary(ctl, q):
     return res
 
 
-def pmc_traffic(cfg, n, sha):
+def pmc_traffic(cfg, n, sha, kernel):
     """HBM bytes per launch from a committed PMC pass of this workload AND these kernel sources
     (profiles/rNN_cfg<cfg>.json, produced by tools/profile_r.sh + tools/summarize_profile.py: separate --pmc
     FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per MI355X_MICROARCH.md).  None if no matching pass:
@@ -296,7 +296,8 @@ def pmc_traffic(cfg, n, sha):
         try:
             d = json.load(open(f))
             bl = d.get("bench_line", {})
-            if bl.get("config", {}).get("robots_per_gpu") == n and bl.get("kernel_src_sha16") == sha and "traffic" in d:
+            if (bl.get("config", {}).get("robots_per_gpu") == n and bl.get("config", {}).get("kernel") == kernel
+                    and bl.get("kernel_src_sha16") == sha and "traffic" in d):
                 best = (d["traffic"]["hbm_bytes_per_launch"], os.path.relpath(f, ROOT))
         except Exception:
             pass
@@ -452,7 +453,7 @@ def main():
         if gather_s is not None:
             line["result_gather"] = {"bytes_per_rank": n * 96, "seconds": gather_s, "GBs_per_rank": n * 96 * (world - 1) / gather_s / 1e9,
                                      "what": "all-gather of the [n, 12] GRF blocks after the timed region (not part of value)"}
-        tr = pmc_traffic(cfg, n, sha)
+        tr = pmc_traffic(cfg, n, sha, ctl.kernel_name)
         if tr is not None:
             line["roofline"]["traffic"] = tr[0]
             line["roofline"]["traffic_source"] = tr[1] + " (rocprofv3 --pmc passes of this command on these kernel sources)"
