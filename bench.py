@@ -467,16 +467,16 @@ def main():
             for c in (2, 3, 4):
                 if c == cfg:
                     continue
-                r = run_config(ctl, q, c, CONFIG_N[c], 0, k, 3, None, device)
+                r = run_config(ctl, q, c, CONFIG_N[c], 0, k, 10, None, device)
                 bp = BYTES_PER_ROBOT_WARM if r["warm"] else BYTES_PER_ROBOT_COLD
                 other[f"config{c}"] = {"robots": CONFIG_N[c], "solved_fraction": r["solved_all_sets"] / (r["sets"] * CONFIG_N[c]), "sets": r["sets"],
                                        "cold_cache": rates(r, "cold", CONFIG_N[c], k, bp), "warm_cache": rates(r, "warm_cache", CONFIG_N[c], k, bp)}
                 del r
                 torch.cuda.empty_cache()
             # the N = 1 point of the config-5 scaling curve: the full 2,097,152-robot batch on this GPU (1 GB: cold by size)
-            r = run_config(ctl, q, 5, CONFIG5_TOTAL, 0, 5, 2, None, device, protocols=("cold",))
+            r = run_config(ctl, q, 5, CONFIG5_TOTAL, 0, 10, 5, None, device, protocols=("cold",))
             other["config5_n1"] = {"robots": CONFIG5_TOTAL, "solved_fraction": r["solved"] / CONFIG5_TOTAL,
-                                   "cold_cache": rates(r, "cold", CONFIG5_TOTAL, 5, BYTES_PER_ROBOT_COLD),
+                                   "cold_cache": rates(r, "cold", CONFIG5_TOTAL, 10, BYTES_PER_ROBOT_COLD),
                                    "what": "N = 1 point of the strong-scaling curve that `bench.py --gpus N` (N > 1) continues"}
             del r
             torch.cuda.empty_cache()
