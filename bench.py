@@ -230,7 +230,9 @@ def batch_load_probe(q, P, device, nb=2097152, steps=10):
 
     from quadruped_control_amd import workloads as W
 
-    probe = q.BalanceController.from_params(P, device=device).set_tuning(probe_batch_load=1)
+    # one_fill=1: the one-lane-per-robot one-fill kernel, i.e. the instantiation every per-GPU batch of configs 3-5 runs on
+    # (the planner would hand a COLD 2 M-robot batch to the persistent kernel; warm-started ones stay one-fill at any size)
+    probe = q.BalanceController.from_params(P, device=device).set_tuning(probe_batch_load=1, one_fill=1)
     base = q.to_device(W.config5(nb // 8), device)
     batch = {k: v.repeat(8, 1).contiguous() for k, v in base.items()}
     out = {"grf_body": torch.empty((nb, 12), dtype=torch.float64, device=f"cuda:{device}"),

@@ -470,21 +470,23 @@ QC_DEV void flush_out(const DevParams* __restrict__ Pg, const BatchIn& in, const
   }
 }
 
-// Two lanes per robot: once at most 16 robots of a wave are still running they fit a 4-lanes-per-robot layout,
-// whose recalculation is 30 % shorter (620 vs 894 instructions) - and the wave waits for exactly these stragglers.
-// The running robots are re-packed through the (now idle) input stock and finish on the G = 4 body; `slot` is
-// where the robot's result goes in the output stock.  `bm` = ballot(busy), popcount <= 32.
-template <bool KIN, bool UNIFORM, int SP, class Lane2>
-QC_DEV void finish_on_four_lanes(const DevParams* __restrict__ Pg, const Lane2& L, bool busy, unsigned long long bm, int slot, int member, int lane,
+// One or two lanes per robot: once at most 16 robots of a wave are still running they fit a 4-lanes-per-robot layout,
+// whose recalculation is much shorter (487 instructions against 730 at two lanes and ~1170 at one) - and the wave
+// waits for exactly these stragglers.  The running robots are re-packed through the (now idle) input stock and finish
+// on the G = 4 body; `slot` is where the robot's result goes in the output stock.  `bm` = ballot(busy), at most
+// 16 robots.
+template <bool KIN, bool UNIFORM, int SP, class LaneG>
+QC_DEV void finish_on_four_lanes(const DevParams* __restrict__ Pg, const LaneG& L, bool busy, unsigned long long bm, int slot, int member, int lane,
                                  double* __restrict__ sin, double* __restrict__ sout) {
   using Eqp4 = EqpDiagW<UNIFORM, 4, !QC_NO_STRIDED>;
   using Lane4 = Lane<Eqp4, KIN>;
   constexpr bool STR4 = Eqp4::kStrided;
-  const int nb = __builtin_popcountll(bm) / 2;  // running robots
+  constexpr int GS = LaneG::G, FPL = LaneG::FPL;  // lanes per robot / feet per lane of the layout being left
+  const int nb = __builtin_popcountll(bm) / GS;  // running robots
   if (nb == 0) return;
   constexpr int RS = 37;  // record stride in doubles (odd: the four lanes of a group read different banks)
   static_assert(16 * RS <= IN_PLANES * SP, "the re-pack records live in the idle input stock");
-  const int rank2 = __builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0)) / 2;
+  const int rank2 = __builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0)) / GS;
   __syncthreads();  // nobody reads the input stock any more
 #define QC_REC(rank, f) sin[(rank) * RS + (f)]
   if (busy) {
@@ -495,8 +497,8 @@ QC_DEV void finish_on_four_lanes(const DevParams* __restrict__ Pg, const Lane2& 
       QC_REC(rank2, 7) = __longlong_as_double((long long)(((unsigned long long)(uint32_t)((L.iters << 8) | slot) << 32) | L.stance));
     }
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
-      const int ft = 2 * member + i;
+    for (int i = 0; i < FPL; i++) {
+      const int ft = FPL * member + i;
 #pragma unroll
       for (int k = 0; k < 3; k++) {
         QC_REC(rank2, 8 + 3 * ft + k) = L.Wr.r[i][k];
@@ -634,7 +636,7 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
     }
     if constexpr (Eqp::kRepackTail) {
       unsigned long long bm = __builtin_amdgcn_ballot_w64(busy);
-      while (__builtin_popcountll(bm) > 32) {
+      while (__builtin_popcountll(bm) > 16 * G) {  // more than 16 robots still running
         if (busy) busy = !L.template iterate<LaneT::STEADY>(*QC_PARAMS_HERE(Pg), eqp);
         bm = __builtin_amdgcn_ballot_w64(busy);
       }
@@ -835,19 +837,20 @@ static int upload_params(qc_handle* h) {
 }
 
 // ---------------------------------------------------------------- launch planning
-// One wave per 64-thread block; a group of G lanes per robot.  The group width trades latency for throughput:
-// G = 4 (foot per lane) has the shortest recalculation (536 instructions per wave against 894 at G = 2 and 1330
-// at G = 1) and is used while four lanes per robot still fit the resident waves - such a batch cannot fill the
-// chip anyway and the slowest robot's serial chain is what is timed; G = 2 costs the same lane-instructions per
-// robot as G = 1, halves the latency and suffers less from iteration-count divergence, so it serves every larger
-// batch of the 6x6 forms.  Batches that fit `rounds` times the resident one-fill workgroups run as one-fill
-// workgroups (the hardware scheduler does the refill); larger ones as persistent waves walking contiguous chunks.
+// One wave per 64-thread block; a group of G lanes per robot.  The group width trades latency for throughput
+// (instructions per steady recalculation: 487 per 16 robots at G = 4, 730 per 32 at G = 2, ~1170 per 64 at G = 1):
+// the planner takes the widest group with which the batch still fits ONE wave per SIMD - such a batch cannot fill
+// the chip anyway and the slowest robot's serial chain is what is timed - i.e. G = 4 up to CUs x 4 x 16 robots
+// (16 384), G = 2 up to twice that, and one lane per robot above (tools/size_scan.py: the cross-overs sit exactly
+// there, cold and warm).  Every width finishes its last <= 16 running robots on the 4-lane body.  Batches up to
+// `rounds` times the resident one-fill workgroups run as one-fill workgroups (the hardware scheduler does the
+// refill: 12 rounds cold, any size warm-started); larger cold ones as persistent waves walking contiguous chunks.
 enum { QC_FORM_UNIFORM = 0, QC_FORM_GENERAL = 1, QC_FORM_DENSE = 2 };
 #ifndef QC_ROUNDS_COLD
-#define QC_ROUNDS_COLD 1.0
+#define QC_ROUNDS_COLD 12.0
 #endif
 #ifndef QC_ROUNDS_WARM
-#define QC_ROUNDS_WARM 6.0
+#define QC_ROUNDS_WARM 1.0e9
 #endif
 
 template <class EQP, int MINW, int MODE>
@@ -869,11 +872,11 @@ static qc_kernel_fn kernel_for(int form, int G, int mode, bool kin, int minw = 2
   if (form == QC_FORM_GENERAL) {
     if (G == 4) return mode ? kernel_of<EqpDiagW<false, 4, STR>, 2, 1>(kin) : kernel_of<EqpDiagW<false, 4>, 2, 0>(kin);
     if (G == 2) return mode ? kernel_of<EqpDiagW<false, 2>, 2, 1>(kin) : kernel_of<EqpDiagW<false, 2>, 2, 0>(kin);
-    return kernel_of<EqpDiagW<false, 1>, 2, 0>(kin);
+    return mode ? kernel_of<EqpDiagW<false, 1>, 2, 1>(kin) : kernel_of<EqpDiagW<false, 1>, 2, 0>(kin);
   }
   if (G == 4) return mode == 2 ? kernel_of<EqpDiagW<true, 4, STR>, 2, 2>(kin) : (mode ? kernel_of<EqpDiagW<true, 4, STR>, 2, 1>(kin) : kernel_of<EqpDiagW<true, 4>, 2, 0>(kin));
   if (G == 2) return mode ? kernel_of<EqpDiagW<true, 2>, 2, 1>(kin) : kernel_of<EqpDiagW<true, 2>, 2, 0>(kin);
-  return kernel_of<EqpDiagW<true, 1>, 2, 0>(kin);
+  return mode ? kernel_of<EqpDiagW<true, 1>, 2, 1>(kin) : kernel_of<EqpDiagW<true, 1>, 2, 0>(kin);
 }
 static size_t lds_for(int form, int G, int mode) {
   const size_t stock = (size_t)qc::stock_doubles(qc::stock_slots(G, mode)) * sizeof(double);
@@ -907,9 +910,10 @@ struct qc_launch_plan {
 static int plan_launch(qc_handle* h, long n, bool kin, bool warm, qc_launch_plan* lp) {
   const int form = !h->diag_w ? QC_FORM_DENSE : (h->uniform ? QC_FORM_UNIFORM : QC_FORM_GENERAL);
   int G = 1;
+  const long simds = (long)h->cus * 4;
   const long cap4 = resident_workgroups(h, kernel_for(form, 4, 1, kin, h->min_waves), lds_for(form, 4, 1)) * 16;
   if (form != QC_FORM_DENSE) {
-    G = n <= cap4 ? 4 : 2;
+    G = n <= 16 * simds ? 4 : (n <= 32 * simds ? 2 : 1);
     if (h->group_override) G = h->group_override;
   } else {
     // dense form: four lanes per robot (one-fill workgroups only) while the batch fits the resident waves - the
@@ -919,18 +923,16 @@ static int plan_launch(qc_handle* h, long n, bool kin, bool warm, qc_launch_plan
     if (G == 4 && (h->one_fill_override == 0 || h->chunk_override > 16)) G = 1;
   }
   const long rpw = 64 / G;  // robots per wave fill
-  // G = 1 of the 6x6 forms has no one-fill instantiation (development width only)
-  const bool can_one_fill = form == QC_FORM_DENSE || G > 1;
+  const bool can_one_fill = true;
   bool one_fill = false;
   long resident = 0;
   if (can_one_fill) {
     resident = resident_workgroups(h, kernel_for(form, G, 1, kin, h->min_waves), lds_for(form, G, 1));
     const double rounds = warm ? h->rounds_warm : h->rounds_cold;
     one_fill = (double)n <= rounds * (double)(resident * rpw);
-    // The joint_q / joint_tau variants carry the kinematics through the persistent loop and spill 300-400 B per
-    // lane there; as one-fill workgroups they stay at 68 B and win at every size (complete tick, 1 M robots:
-    // 1570 -> 941 us).
-    if (kin && G > 1) one_fill = true;
+    // The joint_q / joint_tau variants carry the kinematics through the persistent loop and spill 400-700 B per
+    // lane there; as one-fill workgroups they stay at <= 68 B and win at every size.
+    if (kin) one_fill = true;
     if (h->one_fill_override >= 0) one_fill = h->one_fill_override != 0;
     if (h->chunk_override > 0) one_fill = h->chunk_override <= rpw;
     if (form == QC_FORM_DENSE && G == 4) one_fill = true;

@@ -908,7 +908,7 @@ struct EqpDiagW {
   static constexpr int G = GROUP;
   static constexpr bool kStrided = STRIDED;  // lane layout of the group, see group_sum
   static constexpr bool kUniform = UNIFORM;
-  static constexpr bool kRepackTail = GROUP == 2;  // one-fill waves finish their stragglers 4 lanes per robot
+  static constexpr bool kRepackTail = GROUP <= 2;  // one-fill waves finish their stragglers 4 lanes per robot
   FootW lane_w[4 / GROUP];  // general form with lane groups: the weights of this lane's feet (dead otherwise)
   QC_DEV explicit EqpDiagW(double*) {}
   // called when the lane takes a robot; `foot0` = first foot of the lane

@@ -53,14 +53,6 @@ def test_bench_line_single_gpu(built):
     assert len(d["kernel_src_sha16"]) == 16
 
 
-def test_gpus_flag_must_match_the_launcher(built):
-    """bench.py --gpus 2 under a launcher that made a different world fails instead of printing n_gpus: 1."""
-    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
-    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-sweep", "--no-cpu-baseline"],
-                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode != 0 and "does not match WORLD_SIZE" in (r.stderr + r.stdout)
-
-
 def _check_two_rank_line(d, total):
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["global_batch"] == total
     assert d["config"]["robots_per_gpu"] == total // 2 and d["config"]["workload"].startswith("config5")

@@ -20,6 +20,7 @@ FORM_ID = {"uniform": 0, "general": 1, "dense": 2}
 CASES = []
 for form in ("uniform", "general"):
     CASES += [(form, 1, 0, dict(group=1, chunk=256), 8192),
+              (form, 1, 1, dict(group=1, one_fill=1), 8200),  # ragged: the last wave holds 8 robots
               (form, 2, 0, dict(group=2, chunk=256), 8192),
               (form, 2, 1, dict(group=2, one_fill=1), 8200),  # ragged: the last wave holds 8 robots
               (form, 4, 0, dict(group=4, chunk=128), 8192),
@@ -116,7 +117,7 @@ def test_kernel_instantiation_vs_oracle(q, form, G, mode, tune, n, start):
         assert _relerr(again["grf_body"].cpu().numpy(), ref) < RTOL
 
 
-KIN_CASES = [c for c in CASES if not (c[0] != "dense" and c[1] == 1)]  # every G > 1 branch and both dense widths + [c for c in CASES if c[0] == "uniform" and c[1] == 1]
+KIN_CASES = [c for c in CASES if not (c[0] != "dense" and c[1] == 1 and c[2] == 0)]  # every one-fill branch, every G > 1 branch, both dense widths + [c for c in CASES if c[0] == "uniform" and c[1] == 1]
 
 
 @pytest.mark.parametrize("form,G,mode,tune,n", KIN_CASES, ids=[f"kin-{f}-G{g}-mode{m}" for f, g, m, _, _ in KIN_CASES])

@@ -95,3 +95,21 @@ def test_workloads_deterministic_and_shardable():
     assert np.all(t0["stance"] == 1) and not np.array_equal(t0["x"], t1["x"])
     c1 = W.config1()
     np.testing.assert_allclose(c1["feet"].reshape(4, 3)[:, 2], -0.26)
+
+
+def test_bench_gpus_flag_is_not_ignored():
+    """`bench.py --gpus N` used to be parsed and ignored.  Under a launcher that made a different world
+    it must fail; without a launcher it must start N ranks itself - or say why it cannot (no GPUs here)."""
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "QC_BENCH_ONE_DEVICE")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1"], cwd=ROOT,
+                       env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "does not match WORLD_SIZE=1" in (r.stderr + r.stdout)
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1"], cwd=ROOT, env=env,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and "--gpus 2 but only" in (r.stderr + r.stdout)

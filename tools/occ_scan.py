@@ -27,7 +27,7 @@ def timeit(ctl, b, warm, reps=20):
     return e0.elapsed_time(e1) / reps * 1e3, out
 
 
-VARIANTS = [dict(), dict(group=2, one_fill=1), dict(group=2, one_fill=1, min_waves=3), dict(group=2, one_fill=1, min_waves=4),
+VARIANTS = [dict(), dict(group=1, one_fill=1), dict(group=2, one_fill=1), dict(group=2, one_fill=1, min_waves=3), dict(group=2, one_fill=1, min_waves=4),
             dict(group=4, one_fill=1), dict(group=4, one_fill=1, min_waves=3), dict(group=4, one_fill=1, min_waves=4),
             dict(group=2, one_fill=0), dict(group=4, one_fill=0), dict(group=1)]
 work = []
