@@ -230,9 +230,7 @@ def batch_load_probe(q, P, device, nb=2097152, steps=10):
 
     from quadruped_control_amd import workloads as W
 
-    # one_fill=1: the one-lane-per-robot one-fill kernel, i.e. the instantiation every per-GPU batch of configs 3-5 runs on
-    # (the planner would hand a COLD 2 M-robot batch to the persistent kernel; warm-started ones stay one-fill at any size)
-    probe = q.BalanceController.from_params(P, device=device).set_tuning(probe_batch_load=1, one_fill=1)
+    probe = q.BalanceController.from_params(P, device=device).set_tuning(probe_batch_load=1)
     base = q.to_device(W.config5(nb // 8), device)
     batch = {k: v.repeat(8, 1).contiguous() for k, v in base.items()}
     out = {"grf_body": torch.empty((nb, 12), dtype=torch.float64, device=f"cuda:{device}"),
@@ -476,7 +474,7 @@ def main():
                 del r
                 torch.cuda.empty_cache()
             # the N = 1 point of the config-5 scaling curve: the full 2,097,152-robot batch on this GPU (1 GB: cold by size)
-            r = run_config(ctl, q, 5, CONFIG5_TOTAL, 0, 10, 5, None, device, protocols=("cold",))
+            r = run_config(ctl, q, 5, CONFIG5_TOTAL, 0, 10, 10, None, device, protocols=("cold",))
             other["config5_n1"] = {"robots": CONFIG5_TOTAL, "solved_fraction": r["solved"] / CONFIG5_TOTAL,
                                    "cold_cache": rates(r, "cold", CONFIG5_TOTAL, 10, BYTES_PER_ROBOT_COLD),
                                    "what": "N = 1 point of the strong-scaling curve that `bench.py --gpus N` (N > 1) continues"}

@@ -843,11 +843,13 @@ static int upload_params(qc_handle* h) {
 // the chip anyway and the slowest robot's serial chain is what is timed - i.e. G = 4 up to CUs x 4 x 16 robots
 // (16 384), G = 2 up to twice that, and one lane per robot above (tools/size_scan.py: the cross-overs sit exactly
 // there, cold and warm).  Every width finishes its last <= 16 running robots on the 4-lane body.  Batches up to
-// `rounds` times the resident one-fill workgroups run as one-fill workgroups (the hardware scheduler does the
-// refill: 12 rounds cold, any size warm-started); larger cold ones as persistent waves walking contiguous chunks.
+// `rounds` times the resident one-fill workgroups run as one-fill workgroups - the hardware scheduler does the
+// refill; with the one-lane kernel that wins at every size measured (2 M robots cold: 633 us against 676 us as
+// persistent waves), so `rounds` is unbounded for the 6x6 forms and the persistent kernels (waves walking
+// contiguous chunks with lane refill) serve the one-lane dense form and qc_set_tuning("one_fill", 0).
 enum { QC_FORM_UNIFORM = 0, QC_FORM_GENERAL = 1, QC_FORM_DENSE = 2 };
 #ifndef QC_ROUNDS_COLD
-#define QC_ROUNDS_COLD 12.0
+#define QC_ROUNDS_COLD 1.0e9
 #endif
 #ifndef QC_ROUNDS_WARM
 #define QC_ROUNDS_WARM 1.0e9
@@ -928,7 +930,8 @@ static int plan_launch(qc_handle* h, long n, bool kin, bool warm, qc_launch_plan
   long resident = 0;
   if (can_one_fill) {
     resident = resident_workgroups(h, kernel_for(form, G, 1, kin, h->min_waves), lds_for(form, G, 1));
-    const double rounds = warm ? h->rounds_warm : h->rounds_cold;
+    // (the one-lane dense kernel keeps round 1's thresholds: persistent waves beyond one round of cold workgroups)
+    const double rounds = form == QC_FORM_DENSE ? (warm ? 6.0 : 1.0) : (warm ? h->rounds_warm : h->rounds_cold);
     one_fill = (double)n <= rounds * (double)(resident * rpw);
     // The joint_q / joint_tau variants carry the kinematics through the persistent loop and spill 400-700 B per
     // lane there; as one-fill workgroups they stay at <= 68 B and win at every size.

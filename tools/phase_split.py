@@ -19,7 +19,7 @@ def timeit(ctl, b, warm, reps=20):
     for _ in range(reps): launch()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
-for name, tune in (("mode1 G1", dict(group=1, one_fill=1)), ("mode1 G2", dict(group=2, one_fill=1)), ("mode0 G2", dict(group=2, one_fill=0)), ("mode1 G4", dict(group=4, one_fill=1)), ("mode0 G1", dict(group=1))):
+for name, tune in (("mode1 G1", dict(group=1, one_fill=1)), ("mode1 G2", dict(group=2, one_fill=1)), ("mode0 G2", dict(group=2, one_fill=0)), ("mode1 G4", dict(group=4, one_fill=1)), ("mode0 G1", dict(group=1, one_fill=0))):
     row = []
     for cap in (0, 1, 2, 200):
         ctl = q.BalanceController.from_params(P).set_tuning(**tune)
