@@ -114,7 +114,9 @@ def run_config(ctl, q, cfg, n, start, steps, warmup, dist=None, device=0, fused=
     import torch
 
     dev = f"cuda:{device}"
-    batch, prev = make_batch(cfg, n, start)
+    on_device = cfg in (3, 5) and not fused
+    # the host copy of set 0 only feeds cpu_baseline; configs 3 / 5 make theirs on the device (below) and keep a small host sample
+    batch, prev = make_batch(cfg, min(n, 4096) if on_device else n, start)
     if fused:  # SURVEY 8f rows 1+2: joint angles in (device FK), joint torques out (J^T f, clamped)
         from quadruped_control_amd import workloads as W
 
@@ -128,13 +130,24 @@ def run_config(ctl, q, cfg, n, start, steps, warmup, dist=None, device=0, fused=
     is_warm = prev is not None
     sets = rotation_sets(n, is_warm) if ("cold" in protocols and not fused) else 1
     # set 0 is the canonical workload; sets 1.. hold other robots of the same distribution (shifted seed)
-    hosts, prevs = [batch], [prev]
-    for j in range(1, sets):
-        b, p = make_batch(cfg, n, start, seed_shift=0x100 * j)
-        hosts.append(b)
-        prevs.append(p)
-    big = {k: torch.from_numpy(np.concatenate([h[k] for h in hosts])).to(dev) for k in batch}
-    del hosts
+    if cfg in (3, 5) and not fused:
+        # config 3 / 5 inputs are generated on the device, per shard (same counter-based PRNG; the
+        # contact states are bit-identical to the host generator's, the rotations agree to the last ulp)
+        from quadruped_control_amd import workloads as W
+        from quadruped_control_amd import workloads_device as WD
+
+        parts = [WD.config3(n, start=start, seed=W.SEEDS[cfg] + 0x100 * j, device=device) for j in range(sets)]
+        big = {k: torch.cat([p[k] for p in parts]) for k in parts[0]}
+        del parts
+        prevs = [None]
+    else:
+        hosts, prevs = [batch], [prev]
+        for j in range(1, sets):
+            b, p = make_batch(cfg, n, start, seed_shift=0x100 * j)
+            hosts.append(b)
+            prevs.append(p)
+        big = {k: torch.from_numpy(np.concatenate([h[k] for h in hosts])).to(dev) for k in batch}
+        del hosts
     if fused == "full":
         big["swing_state"] = torch.from_numpy(q.new_swing_states(n).view("uint8").reshape(-1).copy()).to(dev)
     out = {"grf_body": torch.empty((sets * n, 12), dtype=torch.float64, device=dev),
@@ -429,7 +442,7 @@ def main():
             "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic",
+            "data": "synthetic" + (" (generated on the device, per shard)" if cfg in (3, 5) else ""),
             "config": {"workload": CONFIG_DESC[cfg].format(n=n), "robots_per_gpu": n, "global_batch": total_robots,
                        "kernel": ctl.kernel_name, "lanes_per_robot": info["lanes_per_robot"], "kernel_mode": info["mode"],
                        "resident_workgroups": info["resident_workgroups"],
@@ -458,7 +471,7 @@ def main():
             line["roofline"]["traffic"] = tr[0]
             line["roofline"]["traffic_source"] = tr[1] + " (rocprofv3 --pmc passes of this command on these kernel sources)"
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(P, res["batch"])
+            line["cpu_baseline"] = cpu_baseline(P, res["batch"])  # (configs 3 / 5: the first 4096 robots of the batch)
         del res
         torch.cuda.empty_cache()
         if world == 1 and not args.no_sweep:

@@ -594,6 +594,7 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
       L.template load_from_stock<SP>(sin, busy ? grp : 0, member);
       eqp.setup(*QC_PARAMS_HERE(Pg), L.Wr, L.foot0);
       busy = busy && !probe;
+      QC_CLK(0, 2);
       {
         bool done;
         if constexpr (RESIDENT) {
@@ -605,6 +606,7 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
         busy = busy && !done;
       }
       while (__builtin_amdgcn_ballot_w64(busy) != 0) {
+        QC_CLK(7, 2);
         bool done;
         if constexpr (RESIDENT) {
           pin_uconst(uc);
@@ -614,9 +616,11 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
         }
         busy = busy && !done;
       }
+      QC_CLK(7, 8);
       if (grp < stock_n) L.template push_result<SP>(sout, grp);
       __syncthreads();
       flush_out<Eqp::G, KIN, STR, SP>(Pg, in, out, sout, stock_n, lane);
+      QC_CLK_END(8);
       return;
     }
     if (busy) {

@@ -113,3 +113,26 @@ def test_bench_gpus_flag_is_not_ignored():
         r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1"], cwd=ROOT, env=env,
                            capture_output=True, text=True, timeout=300)
         assert r.returncode != 0 and "--gpus 2 but only" in (r.stderr + r.stdout)
+
+
+def test_device_generator_matches_the_host_generator_on_cpu():
+    """workloads_device (torch int64 splitmix64) against workloads (numpy uint64): the uniforms and everything decided
+    by them (gait kind, phases, contact states) bit-identical, the rotation matrices / foot positions to the last ulp."""
+    import torch
+
+    from quadruped_control_amd import workloads as W
+    from quadruped_control_amd import workloads_device as D
+
+    idx = np.arange(7, 7 + 4096, dtype=np.uint64)
+    for seed, stream in ((W.SEEDS[5], 0), (W.SEEDS[3], 21), (W.SEEDS[5] + 0x100, 28)):
+        assert np.array_equal(W.uniform(seed, idx, stream), D.uniform(seed, torch.arange(7, 7 + 4096, dtype=torch.int64), stream).numpy())
+    h = W.config5(3000, start=786432)
+    d = D.config5(3000, start=786432, device="cpu")
+    assert set(h) == set(d)
+    for k in h:
+        dd = d[k].numpy()
+        assert dd.dtype == h[k].dtype and dd.shape == h[k].shape and dd.flags["C_CONTIGUOUS"]
+        if k in ("Rwb", "feet"):
+            assert np.max(np.abs(dd - h[k])) < 1e-15
+        else:
+            assert np.array_equal(dd, h[k]), k

@@ -4,19 +4,22 @@ import ctypes as C, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import numpy as np, torch
 from quadruped_control_amd import _lib
-_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "libqc_balance_clk.so")
+_lib.LIB_PATH = os.environ.get("QC_CLK_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "libqc_balance_clk.so")
 import quadruped_control_amd as q
 from quadruped_control_amd import workloads as W
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 cfg = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-# the phase markers bracket the recalculation inside the PERSISTENT loop (mode 0); the one-fill modes carry none
-# between recalculations, so the tool forces mode 0 (adjacent-lane layout: build with -DQC_NO_STRIDED=1)
-ctl = q.BalanceController.from_params(q.cheetah_params(0.6)).set_tuning(one_fill=0, group=int(sys.argv[3]) if len(sys.argv) > 3 else 4)
+# markers bracket the recalculation in the persistent loop (mode 0) and in the strided one-fill loops (G = 4, modes 1 / 2);
+# argv[3] = lanes per robot, argv[4] = 1 forces the persistent kernel
+tune = dict(group=int(sys.argv[3]) if len(sys.argv) > 3 else 4)
+if len(sys.argv) > 4 and sys.argv[4] == "1":
+    tune["one_fill"] = 0
+ctl = q.BalanceController.from_params(q.cheetah_params(0.6)).set_tuning(**tune)
 lib = ctl._lib
 b = q.to_device({2: W.config2, 3: W.config3}[cfg](n))
 launch, out = ctl.plan_batch(b)
-NAMES = ["first restock", "loop/refill/push", "coef + local M", "group reduce", "cholesky", "tri solves", "forces+grad",
+NAMES = ["first restock", "loop/refill/push", "coef + local M", "group reduce", "LDL^T", "tri solves", "forces+grad",
          "ratio/mult/update", "final flush", "(one marker)"]
 buf = (C.c_ulonglong * 16)()
 for _ in range(3):
