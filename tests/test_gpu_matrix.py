@@ -175,3 +175,36 @@ def test_config5_shard_full_size(q):
     assert np.max(np.abs(g4 - grf) / scale) < 1e-8
     hist = np.bincount(b["stance"].sum(axis=1), minlength=5)
     assert hist[2] > 0 and hist[3] > 0 and hist[4] > 0  # mixed 2/3/4-foot contact states
+
+
+@pytest.mark.parametrize("cap", [1, 2, 3, 6, 9])
+def test_iteration_cap_and_bad_inputs_agree_across_widths(q, cap):
+    """The recalculation cap (nWSR_ analogue) and non-finite inputs across the re-pack: a robot that runs out of
+    recalculations - in the one- or two-lane stage or later in the four-lane tail - and a robot with NaN inputs must
+    end with the same status, iteration count and (zero) forces whichever lane-group width solved it."""
+    from quadruped_control_amd import workloads as W
+
+    n = 5000
+    P = q.cheetah_params(0.6)
+    b = W.config3(n, seed=0x5EED00A5)
+    bad = np.arange(7, n, 611)
+    b["x"][bad[::2], 1] = np.nan
+    b["Rwb"][bad[1::2], 4] = np.inf
+    outs = {}
+    for g in (4, 2, 1):
+        ctl = q.BalanceController.from_params(P, max_iter=cap).set_tuning(group=g, one_fill=1)
+        assert ctl.query_launch(n)["lanes_per_robot"] == g
+        outs[g] = ctl.control_batch_host(b, want_iterations=True, want_active_set=True)
+    ref = outs[4]
+    assert (ref["status"][bad] == 3).all() and np.all(ref["grf_body"][bad] == 0.0)
+    capped = ref["status"] == 1
+    assert capped.any() if cap < 9 else True
+    assert np.all(ref["grf_body"][capped] == 0.0) and (ref["iterations"][capped] == cap).all()
+    for g in (2, 1):
+        o = outs[g]
+        assert np.array_equal(o["status"], ref["status"]), g
+        assert np.array_equal(o["iterations"], ref["iterations"]), g
+        ok = ref["status"] == 0
+        scale = np.maximum(1.0, np.abs(ref["grf_body"][ok]).max(axis=1, keepdims=True))
+        assert np.max(np.abs(o["grf_body"][ok] - ref["grf_body"][ok]) / scale) < 1e-8
+        assert np.all(o["grf_body"][~ok] == 0.0)
