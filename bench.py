@@ -377,7 +377,9 @@ def main():
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} does not match WORLD_SIZE={world}")
     dist = None
-    if world > 1:
+    # QC_BENCH_FORCE_DIST=1 (test hook): bring the process group up even for one rank, so that the RCCL code path
+    # (init, barrier, device-tensor all-reduces, the optional gather) executes on a 1-GPU box too
+    if world > 1 or os.environ.get("QC_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist_mod
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -389,7 +391,7 @@ def main():
             torch.cuda.set_device(local_rank)
             dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         dist = dist_mod
-    device = local_rank if world > 1 else 0
+    device = local_rank if dist is not None else 0
     torch.cuda.set_device(device)
 
     P = q.cheetah_params(mu=0.6)

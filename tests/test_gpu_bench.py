@@ -85,6 +85,22 @@ def test_bench_self_launch_two_ranks(built):
     _check_two_rank_line(_last_json(r.stdout), 65536)
 
 
+def test_bench_one_rank_over_rccl(built):
+    """RCCL itself on the 1-GPU box: a one-rank process group with backend "nccl" (QC_BENCH_FORCE_DIST), i.e. the
+    init, the barriers around the timed region, the device-tensor all-reduces of the counters and the result gather
+    all execute on the GPU - what N > 1 adds on top is only more ranks."""
+    env = {k: v for k, v in os.environ.items() if k not in ("QC_BENCH_ONE_DEVICE",)}
+    env.update(QC_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "bench.py", "--gpus", "1", "--steps", "10", "--warmup", "2", "--config", "5",
+           "--robots", "65536", "--no-sweep", "--no-cpu-baseline", "--gather-results"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 1 and d["config"]["global_batch"] == 65536 and d["solved_fraction"] == 1.0
+    assert d["result_gather"]["bytes_per_rank"] == 65536 * 96 and d["result_gather"]["seconds"] > 0
+
+
 def test_bench_two_ranks_rccl(built):
     """Two ranks on two GPUs over RCCL (backend "nccl"): config 5's full 2,097,152-robot batch, one shard per
     GPU.  Runs whenever the box has at least two devices; the driver's 1-GPU box skips it."""
