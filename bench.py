@@ -472,6 +472,17 @@ def main():
         if tr is not None:
             line["roofline"]["traffic"] = tr[0]
             line["roofline"]["traffic_source"] = tr[1] + " (rocprofv3 --pmc passes of this command on these kernel sources)"
+        if world > 1 and scaling == "strong" and not args.no_sweep:
+            # the N = 1 point of this strong-scaling curve, measured in the same run on rank 0's GPU while the other
+            # ranks wait at the final barrier: the WHOLE batch on one device (efficiency = value / (N x this value))
+            del res
+            torch.cuda.empty_cache()
+            r1 = run_config(ctl, q, cfg, total_robots, 0, 10, 10, None, device, protocols=("cold",))
+            line["n1_reference"] = {"robots": total_robots, "value": total_robots * 10 / r1["cold"][0], "avg_kernel_us": r1["cold"][1] / 10 * 1e6,
+                                    "solved_fraction": r1["solved"] / total_robots,
+                                    "what": "the whole batch on rank 0's GPU alone, after the timed region (not part of value)"}
+            res = {"batch": None}
+            del r1
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(P, res["batch"])  # (configs 3 / 5: the first 4096 robots of the batch)
         del res

@@ -59,6 +59,8 @@ def _check_two_rank_line(d, total):
     assert d["solved_fraction"] == 1.0 and d["value"] > 0
     assert abs(d["value"] - total / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     assert "cpu_baseline" not in d  # rank 0 at N = 1 only
+    ref = d["n1_reference"]  # the same batch on one GPU, measured in the same run
+    assert ref["robots"] == total and ref["solved_fraction"] == 1.0 and ref["value"] > 0
 
 
 def test_bench_two_ranks_torchrun(built):
