@@ -535,7 +535,15 @@ QC_DEV void finish_on_four_lanes(const DevParams* __restrict__ Pg, const LaneG& 
     L4.have_f = true;
     eqp4.setup(*QC_PARAMS_HERE(Pg), L4.Wr, j4);
   }
-  if constexpr (STR4) {
+  if constexpr (STR4 && UNIFORM) {
+    // the tail has the registers to keep the recalculation's constants resident, as the mode-2 kernel does
+    UConst uc = load_uconst(*QC_PARAMS_HERE(Pg));
+    while (__builtin_amdgcn_ballot_w64(busy4) != 0) {
+      pin_uconst(uc);
+      const bool done = L4.template iterate<Lane4::STEADY>(uc, eqp4, busy4);
+      busy4 = busy4 && !done;
+    }
+  } else if constexpr (STR4) {
     while (__builtin_amdgcn_ballot_w64(busy4) != 0) {
       const bool done = L4.template iterate<Lane4::STEADY>(*QC_PARAMS_HERE(Pg), eqp4, busy4);
       busy4 = busy4 && !done;
