@@ -204,14 +204,15 @@ int qc_abi_version(void);
 
 /* ABI v4.  Which kernel instantiation a batch of n robots would run on (kin = joint_q given, warm = warm-start
  * words given): lanes per robot, kernel mode (0 persistent waves with lane refill, 1 one fill per wave, 2 one fill
- * and one wave per SIMD with register-resident constants), form (0 uniform 6x6, 1 general 6x6, 2 dense 12x12),
+ * and one wave per SIMD with register-resident constants; batches that leave SIMDs idle even so race 2 or 4 pivoting
+ * strategies per robot there, `strategies`), form (0 uniform 6x6, 1 general 6x6, 2 dense 12x12),
  * robots per wave, grid size, and the workgroups of that kernel the device holds at once (the occupancy query the
  * heuristics use). */
 typedef struct qc_launch_info {
   int32_t lanes_per_robot;
   int32_t mode;
   int32_t form;
-  int32_t reserved;
+  int32_t strategies; /* mode 2: pivoting strategies racing per robot (1, 2 or 4) */
   int64_t chunk;
   int64_t blocks;
   int64_t resident_workgroups;
@@ -223,6 +224,7 @@ int qc_query_launch(qc_handle* h, size_t n, int kin, int warm, qc_launch_info* o
  * library reads NO environment variables).  Keys: "group" (lanes per robot: 0 = heuristic, 1, 2, 4), "one_fill"
  * (-1 heuristic, 0 persistent waves, 1 one-fill workgroups), "chunk" (robots per wave, 0 = heuristic),
  * "wave_slots" (resident workgroups assumed, 0 = occupancy query), "refill_t", "rounds_cold", "rounds_warm",
+ * "race" (-1 heuristic; 0 or 1: one strategy per robot; 2, 4: at most that many racing in the mode-2 kernel),
  * "force_general" / "force_dense" (run the more general formulation on weights that would allow the
  * specialised one; same minimiser), "tol_d" (relative multiplier tolerance), "max_iter", "probe_batch_load"
  * (1: skip the solver iterations - load, assemble, store only; every robot then reports QC_MAX_ITER).

@@ -45,7 +45,7 @@ class QcSwingState(C.Structure):
 
 
 class QcLaunchInfo(C.Structure):
-    _fields_ = [("lanes_per_robot", C.c_int32), ("mode", C.c_int32), ("form", C.c_int32), ("reserved", C.c_int32),
+    _fields_ = [("lanes_per_robot", C.c_int32), ("mode", C.c_int32), ("form", C.c_int32), ("strategies", C.c_int32),
                 ("chunk", C.c_int64), ("blocks", C.c_int64), ("resident_workgroups", C.c_int64), ("lds_bytes", C.c_int64)]
 
 

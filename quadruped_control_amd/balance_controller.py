@@ -105,13 +105,13 @@ class BalanceController:
         return self
 
     def query_launch(self, n, kin=False, warm=False):
-        """Which kernel instantiation a batch of n robots runs on: dict(lanes_per_robot, mode, form, chunk, blocks,
-        resident_workgroups, lds_bytes) - qc_query_launch."""
+        """Which kernel instantiation a batch of n robots runs on: dict(lanes_per_robot, mode, form, strategies,
+        chunk, blocks, resident_workgroups, lds_bytes) - qc_query_launch."""
         info = _lib.QcLaunchInfo()
         rc = self._lib.qc_query_launch(self._h, int(n), int(bool(kin)), int(bool(warm)), C.byref(info))
         if rc != _lib.QC_OK:
             raise RuntimeError(f"qc_query_launch failed ({rc}): {_lib.last_error()}")
-        return {k: int(getattr(info, k)) for k, _ in info._fields_ if k != "reserved"}
+        return {k: int(getattr(info, k)) for k, _ in info._fields_}
 
     @property
     def kernel_name(self):

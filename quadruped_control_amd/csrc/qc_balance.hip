@@ -50,7 +50,13 @@ enum { IN_B = 0, IN_R = 6, IN_FLAGS = 18, IN_IDX = 19, IN_PLANES = 20,
 constexpr int stock_slots(int G, int MODE) { return MODE == 0 ? 64 : 64 / G; }
 constexpr int stock_doubles(int slots) { return ((STOCK_PLANES * (slots + 1) + 63) / 64) * 64; }
 
-template <class Eqp, bool KIN>
+// RACE (mode-2 kernels of batches that leave most SIMDs idle): several lane groups solve the SAME robot with
+// different pivoting strategies and the first to reach the KKT point wins.  A strategy is (nclamp, drop_all):
+// the first `nclamp` recalculations clamp f^ into the frusta keeping the faces already in the set (1 = the
+// classic method; more = further projection steps before the first ratio test), and after a full step either the
+// most negative multiplier is dropped or all negative ones at once.  Every strategy is a primal active-set method
+// that stops only at the KKT point of the strictly convex QP, i.e. at the same minimiser.
+template <class Eqp, bool KIN, bool RACE = false>
 struct Lane {
   static constexpr int G = Eqp::G;
   static constexpr int FPL = 4 / G;  // feet per lane
@@ -63,6 +69,8 @@ struct Lane {
   int foot0;        // first foot of this lane
   int status, iters;
   bool have_f;
+  int nclamp = 1;        // RACE: recalculations that clamp instead of stepping
+  bool drop_all = false;  // RACE: drop every negative multiplier after a full step
 
   template <class PT>
   QC_DEV double lo(const PT& P, int i) const { return ((stance >> (foot0 + i)) & 1u) ? P.fzmin : 0.0; }
@@ -72,8 +80,9 @@ struct Lane {
   // multiplier test on the current face: true if all active faces have
   // lambda >= -tol; otherwise wcode = 3*foot+axis of the most negative one.
   template <class PT>
-  QC_DEV bool multipliers_ok(const PT& P, const double (&g)[3 * FPL], int& wcode) const {
+  QC_DEV bool multipliers_ok(const PT& P, const double (&g)[3 * FPL], int& wcode, int& negmask) const {
     double gs = 1.0;
+    negmask = 0;
 #pragma unroll
     for (int k = 0; k < 3 * FPL; k++) gs = max_abs_nn(gs, g[k]);
     gs = group_max<G, S>(gs);
@@ -87,6 +96,11 @@ struct Lane {
       cand[3 * i + 0] = tag(C.sx[i] != 0 ? lx : QC_BIG, c0 + 0);
       cand[3 * i + 1] = tag(C.sy[i] != 0 ? ly : QC_BIG, c0 + 1);
       cand[3 * i + 2] = tag(C.sz[i] != 0 ? lz : QC_BIG, c0 + 2);
+      if constexpr (RACE) {  // per-axis "this multiplier is negative" for the drop-all strategy
+        const double thr = -P.tol_d * gs;
+        negmask |= ((C.sx[i] != 0 && lx < thr) ? 1 : 0) << (3 * i) | ((C.sy[i] != 0 && ly < thr) ? 2 : 0) << (3 * i) |
+                   ((C.sz[i] != 0 && lz < thr) ? 4 : 0) << (3 * i);
+      }
     }
 #pragma unroll
     for (int w = 3 * FPL; w > 1; w = (w + 1) / 2)
@@ -114,7 +128,8 @@ struct Lane {
     double fh[3 * FPL], g[3 * FPL];
     iters += live ? 1 : 0;
     const bool pd = eqp.solve(P, Wr, C, stance, foot0, fh, g);
-    const bool fresh = PHASE == FIRST ? true : (PHASE == STEADY ? false : !have_f);
+    // RACE, MIXED: the lane's strategy decides (its first `nclamp` recalculations are clamp steps)
+    const bool fresh = PHASE == FIRST ? true : (PHASE == STEADY ? false : (RACE ? iters <= nclamp : !have_f));
     have_f = true;
     // (a) fresh robot: clamp f^ into the frusta.  In MIXED waves fresh robots exist only right
     // after a (re)fill, so the whole block sits behind a wave-uniform branch.
@@ -170,17 +185,21 @@ struct Lane {
     }
     // multiplier test, meaningful when f landed on f^
     const bool at_fh = fresh ? !changed : !blocked;
-    int wcode;
-    const bool opt = multipliers_ok(P, g, wcode);
+    int wcode, negmask;
+    const bool opt = multipliers_ok(P, g, wcode, negmask);
     if (!at_fh) wcode = -1;
+    const bool dall = RACE && drop_all && at_fh;  // this lane's strategy drops every negative multiplier at once
     const bool take_clamp = fresh && changed;
 #pragma unroll
     for (int i = 0; i < FPL; i++) {
       int sx = C.sx[i], sy = C.sy[i], sz = C.sz[i];
       const int b0 = 6 * (foot0 + i), w0 = 3 * (foot0 + i);
-      sx = (bcode == b0 + 0) ? -1 : ((bcode == b0 + 1) ? 1 : ((wcode == w0 + 0) ? 0 : sx));
-      sy = (bcode == b0 + 2) ? -1 : ((bcode == b0 + 3) ? 1 : ((wcode == w0 + 1) ? 0 : sy));
-      sz = (bcode == b0 + 4) ? -1 : ((bcode == b0 + 5) ? 1 : ((wcode == w0 + 2) ? 0 : sz));
+      const bool px = RACE ? (dall ? ((negmask >> (3 * i)) & 1) != 0 : wcode == w0 + 0) : wcode == w0 + 0;
+      const bool py = RACE ? (dall ? ((negmask >> (3 * i)) & 2) != 0 : wcode == w0 + 1) : wcode == w0 + 1;
+      const bool pz = RACE ? (dall ? ((negmask >> (3 * i)) & 4) != 0 : wcode == w0 + 2) : wcode == w0 + 2;
+      sx = (bcode == b0 + 0) ? -1 : ((bcode == b0 + 1) ? 1 : (px ? 0 : sx));
+      sy = (bcode == b0 + 2) ? -1 : ((bcode == b0 + 3) ? 1 : (py ? 0 : sy));
+      sz = (bcode == b0 + 4) ? -1 : ((bcode == b0 + 5) ? 1 : (pz ? 0 : sz));
       C.sx[i] = live ? (take_clamp ? Cc.sx[i] : sx) : C.sx[i];
       C.sy[i] = live ? (take_clamp ? Cc.sy[i] : sy) : C.sy[i];
       C.sz[i] = live ? (take_clamp ? Cc.sz[i] : sz) : C.sz[i];
@@ -556,10 +575,12 @@ QC_DEV void finish_on_four_lanes(const DevParams* __restrict__ Pg, const LaneG& 
 
 // MODE 0: persistent waves (chunks of many fills, lane refill).  MODE 1: the launch gives every wave at most one
 // fill (chunk <= 64 / G).  MODE 2: one fill and the SIMD to itself, recalculation constants resident in VGPRs.
-template <class Eqp, bool KIN, int MIN_WAVES_PER_SIMD, int MODE = 0>
+// RACE (mode 2 only): strategies racing per robot, 1, 2 or 4; a wave then holds 16 / RACE robots (see Lane).
+template <class Eqp, bool KIN, int MIN_WAVES_PER_SIMD, int MODE = 0, int RACE = 1>
 __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const DevParams* __restrict__ Pg, const long n, const BatchIn in,
                                                                          const uint32_t* __restrict__ warm, const BatchOut out, const long chunk,
                                                                          const int refill_t) {
+  static_assert(RACE == 1 || (MODE == 2 && Eqp::kStrided && Eqp::G == 4), "racing strategies exist for the strided mode-2 kernel");
   constexpr int G = Eqp::G;
   extern __shared__ __attribute__((aligned(16))) double qc_lds[];  // [stock planes][64] (+ the dense form's 78 Hessian planes)
   constexpr int SP = stock_slots(G, MODE) + 1;  // plane stride of this mode's stock
@@ -573,7 +594,7 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
   const int member = lane_member<G, STR>(lane);
   int stock_n = 0, stock_next = 0;  // input stock: slots [stock_next, stock_n) hold assembled robots
   int out_n = 0;                    // output stock: slots [0, out_n) hold finished results
-  Lane<Eqp, KIN> L;
+  Lane<Eqp, KIN, (RACE > 1)> L;
   L.idx = -1;
   L.foot0 = member * (4 / G);
   Eqp eqp(qc_lds + stock_doubles(stock_slots(G, MODE)) + lane);
@@ -592,16 +613,44 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
     busy = grp < stock_n;
     // measurement probe (qc_set_tuning "probe_batch_load"): load -> assemble -> store only, no recalculation
     const bool probe = QC_PARAMS_HERE(Pg)->max_iter == 0;
-    using LaneT = Lane<Eqp, KIN>;
+    using LaneT = Lane<Eqp, KIN, (RACE > 1)>;
     if constexpr (STR) {
       // Strided layout: the group sums run on the matrix pipe, and an MFMA reads its operands from ALL 64 lanes
       // whatever EXEC says - the all-ones A operand included, which the compiler materialises under the current
       // EXEC.  So nothing here may run under a partial EXEC: every lane carries a robot (groups beyond the fill
       // shadow robot 0) through a wave-uniform loop, and only the lanes of running robots commit what a
       // recalculation produced.
-      L.template load_from_stock<SP>(sin, busy ? grp : 0, member);
+      // RACE > 1: the wave holds 16 / RACE robots; group grp solves robot grp % ROB with strategy sid
+      constexpr int ROB = 16 / RACE;
+      const int slot = grp & (ROB - 1);
+      const int sid = (grp / ROB) * (4 / RACE);  // 4 strategies: 0 .. 3; 2: {0, 2}
+      if constexpr (RACE > 1) {
+        busy = slot < stock_n;
+        // (clamp steps, drop rule) = (1, most negative) (1, all) (2, all) (3, most negative): over eight 4 096-robot
+        // batches the slowest robot takes 13.25 recalculations on average against 16.9 with the first strategy alone
+        // (13.9 for the pair {0, 2} a 2-way race runs); oracle/prototypes/proto_race_strategies.py
+        L.nclamp = sid == 3 ? 3 : (sid == 2 ? 2 : 1);
+        L.drop_all = sid == 1 || sid == 2;
+      }
+      L.template load_from_stock<SP>(sin, busy ? slot : 0, member);
       eqp.setup(*QC_PARAMS_HERE(Pg), L.Wr, L.foot0);
       busy = busy && !probe;
+      unsigned solved_mask = 0;  // RACE: strategies of this lane's robot that have reached the KKT point
+      // the robot is finished as soon as one strategy has solved it; the others stop with it
+      auto after = [&](bool done) {
+        if constexpr (RACE > 1) {
+          const int mine = (busy && done && L.status == QC_SOLVED) ? (1 << sid) : 0;
+          int m = mine | __builtin_amdgcn_update_dpp(0, mine, 0x120 + ROB, 0xF, 0xF, true);  // row_ror by ROB lanes: the partner groups
+          if constexpr (RACE == 4) {
+            m |= __builtin_amdgcn_update_dpp(0, mine, 0x120 + 2 * ROB, 0xF, 0xF, true);
+            m |= __builtin_amdgcn_update_dpp(0, mine, 0x120 + 3 * ROB, 0xF, 0xF, true);
+          }
+          solved_mask |= (unsigned)m;
+          busy = busy && !done && solved_mask == 0;
+        } else {
+          busy = busy && !done;
+        }
+      };
       QC_CLK(0, 2);
       {
         bool done;
@@ -611,7 +660,16 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
         } else {
           done = L.template iterate<LaneT::FIRST>(*QC_PARAMS_HERE(Pg), eqp, busy);
         }
-        busy = busy && !done;
+        after(done);
+      }
+      if constexpr (RACE > 1) {  // recalculations 2 and 3: clamp steps for the strategies that take them, ordinary steps for the others
+#pragma unroll 1
+        for (int it = 2; it <= 3 && __builtin_amdgcn_ballot_w64(busy) != 0; it++) {
+          QC_CLK(7, 2);
+          pin_uconst(uc);
+          const bool done = L.template iterate<LaneT::MIXED>(uc, eqp, busy);
+          after(done);
+        }
       }
       while (__builtin_amdgcn_ballot_w64(busy) != 0) {
         QC_CLK(7, 2);
@@ -622,7 +680,18 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
         } else {
           done = L.template iterate<LaneT::STEADY>(*QC_PARAMS_HERE(Pg), eqp, busy);
         }
-        busy = busy && !done;
+        after(done);
+      }
+      if constexpr (RACE > 1) {
+        // the winner - the lowest-numbered strategy among those that solved the robot in the deciding
+        // recalculation, or strategy 0 with whatever status it has if none did - parks the result
+        const int win = solved_mask ? __builtin_ctz(solved_mask) : 0;
+        QC_CLK(7, 8);
+        if (slot < stock_n && sid == win) L.template push_result<SP>(sout, slot);
+        __syncthreads();
+        flush_out<Eqp::G, KIN, STR, SP>(Pg, in, out, sout, stock_n, lane);
+        QC_CLK_END(8);
+        return;
       }
       QC_CLK(7, 8);
       if (grp < stock_n) L.template push_result<SP>(sout, grp);
@@ -755,6 +824,7 @@ struct qc_handle {
   int group_override;      // 1, 2, 4: lanes per robot
   int one_fill_override;   // 0: never (persistent waves), 1: always, -1: heuristic
   int wave_slots_override; // > 0: resident workgroups assumed for every kernel instead of the occupancy query
+  int race_override;       // -1 heuristic; 0 / 1: no racing strategies; 2, 4: at most that many per robot
   int min_waves;           // development builds (QC_EXPERIMENTAL_OCC): register cap of the one-fill kernels, waves per SIMD
   // resident workgroups per kernel instantiation (hipOccupancyMaxActiveBlocksPerMultiprocessor x CUs), filled lazily
   struct { qc_kernel_fn fn; size_t lds; long resident; } occ[40];
@@ -867,12 +937,12 @@ enum { QC_FORM_UNIFORM = 0, QC_FORM_GENERAL = 1, QC_FORM_DENSE = 2 };
 #define QC_ROUNDS_WARM 1.0e9
 #endif
 
-template <class EQP, int MINW, int MODE>
+template <class EQP, int MINW, int MODE, int RACE = 1>
 static qc_kernel_fn kernel_of(bool kin) {
-  return kin ? (qc_kernel_fn)qc::balance_kernel<EQP, true, MINW, MODE> : (qc_kernel_fn)qc::balance_kernel<EQP, false, MINW, MODE>;
+  return kin ? (qc_kernel_fn)qc::balance_kernel<EQP, true, MINW, MODE, RACE> : (qc_kernel_fn)qc::balance_kernel<EQP, false, MINW, MODE, RACE>;
 }
 // the kernel instantiation for (form, lanes per robot, mode); mode 2 exists for the uniform G = 4 form only
-static qc_kernel_fn kernel_for(int form, int G, int mode, bool kin, int minw = 2) {
+static qc_kernel_fn kernel_for(int form, int G, int mode, bool kin, int minw = 2, int race = 1) {
   using namespace qc;
   constexpr bool STR = !QC_NO_STRIDED;
 #ifdef QC_EXPERIMENTAL_OCC  // development builds: register-capped one-fill instantiations of the uniform form (tools/occ_scan.py)
@@ -888,6 +958,8 @@ static qc_kernel_fn kernel_for(int form, int G, int mode, bool kin, int minw = 2
     if (G == 2) return mode ? kernel_of<EqpDiagW<false, 2>, 2, 1>(kin) : kernel_of<EqpDiagW<false, 2>, 2, 0>(kin);
     return mode ? kernel_of<EqpDiagW<false, 1>, 2, 1>(kin) : kernel_of<EqpDiagW<false, 1>, 2, 0>(kin);
   }
+  if (G == 4 && mode == 2 && STR && race == 4) return kernel_of<EqpDiagW<true, 4, STR>, 2, 2, (STR ? 4 : 1)>(kin);
+  if (G == 4 && mode == 2 && STR && race == 2) return kernel_of<EqpDiagW<true, 4, STR>, 2, 2, (STR ? 2 : 1)>(kin);
   if (G == 4) return mode == 2 ? kernel_of<EqpDiagW<true, 4, STR>, 2, 2>(kin) : (mode ? kernel_of<EqpDiagW<true, 4, STR>, 2, 1>(kin) : kernel_of<EqpDiagW<true, 4>, 2, 0>(kin));
   if (G == 2) return mode ? kernel_of<EqpDiagW<true, 2>, 2, 1>(kin) : kernel_of<EqpDiagW<true, 2>, 2, 0>(kin);
   return mode ? kernel_of<EqpDiagW<true, 1>, 2, 1>(kin) : kernel_of<EqpDiagW<true, 1>, 2, 0>(kin);
@@ -917,7 +989,7 @@ struct qc_launch_plan {
   size_t lds;
   unsigned blocks;
   long chunk;
-  int refill_t, G, mode;
+  int refill_t, G, mode, race;
   long resident;
 };
 
@@ -952,20 +1024,28 @@ static int plan_launch(qc_handle* h, long n, bool kin, bool warm, qc_launch_plan
     if (h->chunk_override > 0) one_fill = h->chunk_override <= rpw;
     if (form == QC_FORM_DENSE && G == 4) one_fill = true;
   }
-  int mode = 0;
+  int mode = 0, race = 1;
   long chunk;
   if (one_fill) {
     chunk = h->chunk_override > 0 ? h->chunk_override : rpw;
     const long blocks = (n + chunk - 1) / chunk;
     // one wave per SIMD is enough: the recalculation's constants stay resident in VGPRs (uniform G = 4 form)
     mode = (form == QC_FORM_UNIFORM && G == 4 && blocks <= (long)h->cus * 4) ? 2 : 1;
+    // ... and when even that leaves SIMDs idle they race pivoting strategies on the same robot (Lane: RACE):
+    // four per robot up to CUs x 4 x 4 robots (4 096), two up to twice that
+    if (mode == 2 && !QC_NO_STRIDED && h->chunk_override <= 0) {
+      race = n <= 4 * simds ? 4 : (n <= 8 * simds ? 2 : 1);
+      if (h->race_override >= 0) race = (h->race_override == 4 && n <= 4 * simds) ? 4 : ((h->race_override >= 2 && n <= 8 * simds) ? 2 : 1);
+      chunk = 16 / race;
+    }
   } else {
     resident = resident_workgroups(h, kernel_for(form, G, 0, kin), lds_for(form, G, 0));
     chunk = rpw;
     if (n > rpw * resident) chunk = ((n + resident - 1) / resident + 15) / 16 * 16;
     if (h->chunk_override > 0) chunk = h->chunk_override;
   }
-  lp->fn = kernel_for(form, G, mode, kin, h->min_waves);
+  lp->fn = kernel_for(form, G, mode, kin, h->min_waves, race);
+  lp->race = race;
   lp->lds = lds_for(form, G, mode);
   lp->blocks = (unsigned)((n + chunk - 1) / chunk);
   lp->chunk = chunk;
@@ -1143,6 +1223,7 @@ int qc_create(const qc_params* p, int device, qc_handle** out) {
   h->one_fill_override = -1;
   h->wave_slots_override = 0;
   h->min_waves = 2;
+  h->race_override = -1;
   h->n_occ = 0;
   if (hipSetDevice(device) != hipSuccess || hipMalloc((void**)&h->d_params, sizeof(qc::DevParams)) != hipSuccess ||
       hipMemcpy(h->d_params, &h->dp, sizeof(qc::DevParams), hipMemcpyHostToDevice) != hipSuccess) {
@@ -1164,6 +1245,7 @@ int qc_set_tuning(qc_handle* h, const char* key, double value) {
   } else if (k == "one_fill") h->one_fill_override = value < 0 ? -1 : (value != 0 ? 1 : 0);
   else if (k == "chunk") h->chunk_override = value > 0 ? (long)value : 0;
   else if (k == "wave_slots") h->wave_slots_override = value > 0 ? (int)value : 0;
+  else if (k == "race") h->race_override = value < 0 ? -1 : (int)value;
   else if (k == "min_waves") h->min_waves = value > 2 ? (int)value : 2;
   else if (k == "refill_t") h->refill_t = value > 0 ? (int)value : 16;
   else if (k == "rounds_cold") h->rounds_cold = value;
@@ -1200,7 +1282,7 @@ int qc_query_launch(qc_handle* h, size_t n, int kin, int warm, qc_launch_info* o
   out->lanes_per_robot = lp.G;
   out->mode = lp.mode;
   out->form = !h->diag_w ? QC_FORM_DENSE : (h->uniform ? QC_FORM_UNIFORM : QC_FORM_GENERAL);
-  out->reserved = 0;
+  out->strategies = lp.race;
   out->chunk = lp.chunk;
   out->blocks = lp.blocks;
   out->resident_workgroups = resident_workgroups(h, lp.fn, lp.lds);
