@@ -80,9 +80,8 @@ struct Lane {
   // multiplier test on the current face: true if all active faces have
   // lambda >= -tol; otherwise wcode = 3*foot+axis of the most negative one.
   template <class PT>
-  QC_DEV bool multipliers_ok(const PT& P, const double (&g)[3 * FPL], int& wcode, int& negmask) const {
+  QC_DEV bool multipliers_ok(const PT& P, const double (&g)[3 * FPL], int& wcode, bool (&neg)[3 * FPL]) const {
     double gs = 1.0;
-    negmask = 0;
 #pragma unroll
     for (int k = 0; k < 3 * FPL; k++) gs = max_abs_nn(gs, g[k]);
     gs = group_max<G, S>(gs);
@@ -96,10 +95,13 @@ struct Lane {
       cand[3 * i + 0] = tag(C.sx[i] != 0 ? lx : QC_BIG, c0 + 0);
       cand[3 * i + 1] = tag(C.sy[i] != 0 ? ly : QC_BIG, c0 + 1);
       cand[3 * i + 2] = tag(C.sz[i] != 0 ? lz : QC_BIG, c0 + 2);
-      if constexpr (RACE) {  // per-axis "this multiplier is negative" for the drop-all strategy
+      if constexpr (RACE) {  // per-axis "this multiplier is negative" for the drop-all strategy (compares; the masks live in SGPRs)
         const double thr = -P.tol_d * gs;
-        negmask |= ((C.sx[i] != 0 && lx < thr) ? 1 : 0) << (3 * i) | ((C.sy[i] != 0 && ly < thr) ? 2 : 0) << (3 * i) |
-                   ((C.sz[i] != 0 && lz < thr) ? 4 : 0) << (3 * i);
+        neg[3 * i + 0] = C.sx[i] != 0 && lx < thr;
+        neg[3 * i + 1] = C.sy[i] != 0 && ly < thr;
+        neg[3 * i + 2] = C.sz[i] != 0 && lz < thr;
+      } else {
+        neg[3 * i + 0] = neg[3 * i + 1] = neg[3 * i + 2] = false;
       }
     }
 #pragma unroll
@@ -185,8 +187,9 @@ struct Lane {
     }
     // multiplier test, meaningful when f landed on f^
     const bool at_fh = fresh ? !changed : !blocked;
-    int wcode, negmask;
-    const bool opt = multipliers_ok(P, g, wcode, negmask);
+    int wcode;
+    bool neg[3 * FPL];
+    const bool opt = multipliers_ok(P, g, wcode, neg);
     if (!at_fh) wcode = -1;
     const bool dall = RACE && drop_all && at_fh;  // this lane's strategy drops every negative multiplier at once
     const bool take_clamp = fresh && changed;
@@ -194,9 +197,9 @@ struct Lane {
     for (int i = 0; i < FPL; i++) {
       int sx = C.sx[i], sy = C.sy[i], sz = C.sz[i];
       const int b0 = 6 * (foot0 + i), w0 = 3 * (foot0 + i);
-      const bool px = RACE ? (dall ? ((negmask >> (3 * i)) & 1) != 0 : wcode == w0 + 0) : wcode == w0 + 0;
-      const bool py = RACE ? (dall ? ((negmask >> (3 * i)) & 2) != 0 : wcode == w0 + 1) : wcode == w0 + 1;
-      const bool pz = RACE ? (dall ? ((negmask >> (3 * i)) & 4) != 0 : wcode == w0 + 2) : wcode == w0 + 2;
+      const bool px = RACE ? (dall ? neg[3 * i + 0] : wcode == w0 + 0) : wcode == w0 + 0;
+      const bool py = RACE ? (dall ? neg[3 * i + 1] : wcode == w0 + 1) : wcode == w0 + 1;
+      const bool pz = RACE ? (dall ? neg[3 * i + 2] : wcode == w0 + 2) : wcode == w0 + 2;
       sx = (bcode == b0 + 0) ? -1 : ((bcode == b0 + 1) ? 1 : (px ? 0 : sx));
       sy = (bcode == b0 + 2) ? -1 : ((bcode == b0 + 3) ? 1 : (py ? 0 : sy));
       sz = (bcode == b0 + 4) ? -1 : ((bcode == b0 + 5) ? 1 : (pz ? 0 : sz));
@@ -575,12 +578,12 @@ QC_DEV void finish_on_four_lanes(const DevParams* __restrict__ Pg, const LaneG& 
 
 // MODE 0: persistent waves (chunks of many fills, lane refill).  MODE 1: the launch gives every wave at most one
 // fill (chunk <= 64 / G).  MODE 2: one fill and the SIMD to itself, recalculation constants resident in VGPRs.
-// RACE (mode 2 only): strategies racing per robot, 1, 2 or 4; a wave then holds 16 / RACE robots (see Lane).
+// RACE (strided 4-lane one-fill kernels): strategies racing per robot, 1, 2 or 4; a wave then holds 16 / RACE robots (see Lane).
 template <class Eqp, bool KIN, int MIN_WAVES_PER_SIMD, int MODE = 0, int RACE = 1>
 __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const DevParams* __restrict__ Pg, const long n, const BatchIn in,
                                                                          const uint32_t* __restrict__ warm, const BatchOut out, const long chunk,
                                                                          const int refill_t) {
-  static_assert(RACE == 1 || (MODE == 2 && Eqp::kStrided && Eqp::G == 4), "racing strategies exist for the strided mode-2 kernel");
+  static_assert(RACE == 1 || (MODE != 0 && Eqp::kStrided && Eqp::G == 4), "racing strategies exist for the strided one-fill kernels");
   constexpr int G = Eqp::G;
   extern __shared__ __attribute__((aligned(16))) double qc_lds[];  // [stock planes][64] (+ the dense form's 78 Hessian planes)
   constexpr int SP = stock_slots(G, MODE) + 1;  // plane stride of this mode's stock
@@ -666,8 +669,13 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
 #pragma unroll 1
         for (int it = 2; it <= 3 && __builtin_amdgcn_ballot_w64(busy) != 0; it++) {
           QC_CLK(7, 2);
-          pin_uconst(uc);
-          const bool done = L.template iterate<LaneT::MIXED>(uc, eqp, busy);
+          bool done;
+          if constexpr (RESIDENT) {
+            pin_uconst(uc);
+            done = L.template iterate<LaneT::MIXED>(uc, eqp, busy);
+          } else {
+            done = L.template iterate<LaneT::MIXED>(*QC_PARAMS_HERE(Pg), eqp, busy);
+          }
           after(done);
         }
       }
@@ -952,8 +960,11 @@ static qc_kernel_fn kernel_for(int form, int G, int mode, bool kin, int minw = 2
   }
 #endif
   (void)minw;
-  if (form == QC_FORM_DENSE) return G == 4 ? kernel_of<EqpDense4, 1, 1>(kin) : (mode ? kernel_of<EqpDense, 1, 1>(kin) : kernel_of<EqpDense, 1, 0>(kin));
+  if (form == QC_FORM_DENSE && G == 4) return race == 4 ? kernel_of<EqpDense4, 1, 1, 4>(kin) : (race == 2 ? kernel_of<EqpDense4, 1, 1, 2>(kin) : kernel_of<EqpDense4, 1, 1>(kin));
+  if (form == QC_FORM_DENSE) return mode ? kernel_of<EqpDense, 1, 1>(kin) : kernel_of<EqpDense, 1, 0>(kin);
   if (form == QC_FORM_GENERAL) {
+    if (G == 4 && mode && STR && race == 4) return kernel_of<EqpDiagW<false, 4, STR>, 2, 1, (STR ? 4 : 1)>(kin);
+    if (G == 4 && mode && STR && race == 2) return kernel_of<EqpDiagW<false, 4, STR>, 2, 1, (STR ? 2 : 1)>(kin);
     if (G == 4) return mode ? kernel_of<EqpDiagW<false, 4, STR>, 2, 1>(kin) : kernel_of<EqpDiagW<false, 4>, 2, 0>(kin);
     if (G == 2) return mode ? kernel_of<EqpDiagW<false, 2>, 2, 1>(kin) : kernel_of<EqpDiagW<false, 2>, 2, 0>(kin);
     return mode ? kernel_of<EqpDiagW<false, 1>, 2, 1>(kin) : kernel_of<EqpDiagW<false, 1>, 2, 0>(kin);
@@ -1031,10 +1042,12 @@ static int plan_launch(qc_handle* h, long n, bool kin, bool warm, qc_launch_plan
     const long blocks = (n + chunk - 1) / chunk;
     // one wave per SIMD is enough: the recalculation's constants stay resident in VGPRs (uniform G = 4 form)
     mode = (form == QC_FORM_UNIFORM && G == 4 && blocks <= (long)h->cus * 4) ? 2 : 1;
-    // ... and when even that leaves SIMDs idle they race pivoting strategies on the same robot (Lane: RACE):
-    // four per robot up to CUs x 4 x 4 robots (4 096), two up to twice that
-    if (mode == 2 && !QC_NO_STRIDED && h->chunk_override <= 0) {
-      race = n <= 4 * simds ? 4 : (n <= 8 * simds ? 2 : 1);
+    // ... and when even that leaves SIMDs idle the 4-lane kernels (all three forms) race pivoting strategies on the
+    // same robot (Lane: RACE): four per robot up to CUs x 4 x 4 robots (4 096)
+    if (G == 4 && !QC_NO_STRIDED && h->chunk_override <= 0 && (mode == 2 || form != QC_FORM_UNIFORM)) {
+      // (a 2-way race up to 8 192 robots is built and selectable - qc_set_tuning("race", 2) - but measured neutral on
+      // average: its two fewer recalculations pay for the heavier body, tools/race_scan.py)
+      race = n <= 4 * simds ? 4 : 1;
       if (h->race_override >= 0) race = (h->race_override == 4 && n <= 4 * simds) ? 4 : ((h->race_override >= 2 && n <= 8 * simds) ? 2 : 1);
       chunk = 16 / race;
     }
