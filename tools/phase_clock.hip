@@ -9,7 +9,7 @@
 #include <hip/hip_runtime.h>
 __device__ unsigned long long qc_clk_global[16];
 __shared__ unsigned long long qc_clk_lds[16];
-#define QC_CLK_ELECT() (__lane_id() == (unsigned)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true)))
+#define QC_CLK_ELECT() (threadIdx.x < 64 && __lane_id() == (unsigned)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true)))  // wave 0 of the workgroup
 #define QC_CLK(from, to)                                                               \
   do {                                                                                 \
     const unsigned long long t_ = __builtin_readcyclecounter();                        \

@@ -1,5 +1,5 @@
 """Development tool: where the cycles of one wave go (needs tools/_build/libqc_balance_clk.so, see phase_clock.hip).
-usage: python tools/phase_clock.py [n=4096] [config=2] [lanes per robot=4]"""
+usage: python tools/phase_clock.py [n=4096] [config=2] [lanes per robot=4] [persistent=0] [key=value ...]"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import numpy as np, torch
@@ -15,6 +15,9 @@ cfg = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 tune = dict(group=int(sys.argv[3]) if len(sys.argv) > 3 else 4)
 if len(sys.argv) > 4 and sys.argv[4] == "1":
     tune["one_fill"] = 0
+for kv in sys.argv[5:]:  # further tuning keys, e.g. race=0
+    k, v = kv.split("=")
+    tune[k] = float(v)
 ctl = q.BalanceController.from_params(q.cheetah_params(0.6)).set_tuning(**tune)
 lib = ctl._lib
 b = q.to_device({2: W.config2, 3: W.config3}[cfg](n))
