@@ -212,7 +212,7 @@ typedef struct qc_launch_info {
   int32_t lanes_per_robot;
   int32_t mode;
   int32_t form;
-  int32_t strategies; /* mode 2: pivoting strategies racing per robot (1, 2 or 4) */
+  int32_t strategies; /* four lanes per robot, one-fill kernels: pivoting strategies racing per robot (1, 2 or 4) */
   int64_t chunk;
   int64_t blocks;
   int64_t resident_workgroups;
@@ -224,9 +224,11 @@ int qc_query_launch(qc_handle* h, size_t n, int kin, int warm, qc_launch_info* o
  * library reads NO environment variables).  Keys: "group" (lanes per robot: 0 = heuristic, 1, 2, 4), "one_fill"
  * (-1 heuristic, 0 persistent waves, 1 one-fill workgroups), "chunk" (robots per wave, 0 = heuristic),
  * "wave_slots" (resident workgroups assumed, 0 = occupancy query), "refill_t", "rounds_cold", "rounds_warm",
- * "race" (-1 heuristic; 0 or 1: one strategy per robot; 2, 4: at most that many racing in the mode-2 kernel),
+ * "race" (-1 heuristic; 0 or 1: one strategy per robot; 2, 4: at most that many racing in the 4-lane one-fill kernels),
  * "force_general" / "force_dense" (run the more general formulation on weights that would allow the
- * specialised one; same minimiser), "tol_d" (relative multiplier tolerance), "max_iter", "probe_batch_load"
+ * specialised one; same minimiser), "clamp_steps" (clamp steps a cold-started robot takes before its first ratio test in
+ * the one-fill kernels; 0 = the kernel's rule: five on one or two lanes per robot, one on four),
+ * "tol_d" (relative multiplier tolerance), "max_iter", "probe_batch_load"
  * (1: skip the solver iterations - load, assemble, store only; every robot then reports QC_MAX_ITER).
  * Calls that change device constants synchronise the device first.  Returns QC_ERR_INVALID for an unknown key. */
 int qc_set_tuning(qc_handle* h, const char* key, double value);

@@ -579,6 +579,18 @@ QC_DEV void finish_on_four_lanes(const DevParams* __restrict__ Pg, const LaneG& 
 // MODE 0: persistent waves (chunks of many fills, lane refill).  MODE 1: the launch gives every wave at most one
 // fill (chunk <= 64 / G).  MODE 2: one fill and the SIMD to itself, recalculation constants resident in VGPRs.
 // RACE (strided 4-lane one-fill kernels): strategies racing per robot, 1, 2 or 4; a wave then holds 16 / RACE robots (see Lane).
+// How many of a cold-started robot's first recalculations are CLAMP steps (project the equality-constrained minimiser
+// of the current working set into the frusta, keep the faces it hits) before the ratio-test steps start.  One is the
+// classic start.  More of them build the working set several faces at a time and cost less than a ratio-test step:
+// five are the measured optimum where the batch fills the chip (one or two lanes per robot: 262 144 robots 104 -> 95 us,
+// 1 M robots 345 -> 291 us; more than six start to cycle - profiles/r02_clamp_scan.log); the 4-lane kernels (chain-bound
+// batches) do not care, and a warm-started robot already has its working set: further clamp steps only disturb it.
+template <int G>
+QC_DEV int clamp_steps_for(CParams& P, const uint32_t* warm) {
+  const int tuned = P.clamp_steps;  // qc_set_tuning "clamp_steps"; 0 = this rule
+  return tuned > 0 ? tuned : ((warm != nullptr || G == 4) ? 1 : 5);
+}
+
 template <class Eqp, bool KIN, int MIN_WAVES_PER_SIMD, int MODE = 0, int RACE = 1>
 __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const DevParams* __restrict__ Pg, const long n, const BatchIn in,
                                                                          const uint32_t* __restrict__ warm, const BatchOut out, const long chunk,
@@ -655,7 +667,11 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
         }
       };
       QC_CLK(0, 2);
-      {
+      // clamp steps: one for the racing lanes (their strategies take more in the MIXED recalculations below)
+      const int first_steps = RACE > 1 ? 1 : clamp_steps_for<G>(*QC_PARAMS_HERE(Pg), warm);
+#pragma unroll 1
+      for (int k = 0; k < first_steps && (k == 0 || __builtin_amdgcn_ballot_w64(busy) != 0); k++) {
+        if (k) QC_CLK(7, 2);
         bool done;
         if constexpr (RESIDENT) {
           pin_uconst(uc);
@@ -715,12 +731,17 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
     const bool mine = busy;
     busy = busy && !probe;
     QC_CLK(0, 2);
-    if (busy) {  // every robot of a one-fill wave is fresh exactly once: the clamp step is peeled
-      if constexpr (RESIDENT) {
-        pin_uconst(uc);
-        busy = !L.template iterate<LaneT::FIRST>(uc, eqp);
-      } else {
-        busy = !L.template iterate<LaneT::FIRST>(*QC_PARAMS_HERE(Pg), eqp);
+    const int first_steps = clamp_steps_for<G>(*QC_PARAMS_HERE(Pg), warm);
+#pragma unroll 1
+    for (int k = 0; k < first_steps; k++) {
+      if (k) QC_CLK(7, 2);
+      if (busy) {  // every robot of a one-fill wave is fresh exactly once: the clamp steps are peeled
+        if constexpr (RESIDENT) {
+          pin_uconst(uc);
+          busy = !L.template iterate<LaneT::FIRST>(uc, eqp);
+        } else {
+          busy = !L.template iterate<LaneT::FIRST>(*QC_PARAMS_HERE(Pg), eqp);
+        }
       }
     }
     if constexpr (Eqp::kRepackTail) {
@@ -1225,6 +1246,7 @@ int qc_create(const qc_params* p, int device, qc_handle** out) {
   // and change neither the recalculation counts of 1 M robots nor anything else measurable).
   d.tol_d = 1e-14;
   d.max_iter = p->max_iter > 0 ? p->max_iter : 200;
+  d.clamp_steps = 0;  // 0: per kernel (clamp_steps_for)
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete h; return fail(QC_ERR_HIP, "qc_create: hipGetDeviceProperties failed"); }
   h->cus = prop.multiProcessorCount;
@@ -1279,6 +1301,7 @@ int qc_set_tuning(qc_handle* h, const char* key, double value) {
     h->diag_w = value != 0 ? false : diag;
   } else if (k == "tol_d") { h->dp.tol_d = value; params = true; }
   else if (k == "max_iter") { h->dp.max_iter = value > 0 ? (int)value : 200; params = true; }
+  else if (k == "clamp_steps") { h->dp.clamp_steps = value >= 1 ? (int)value : 0; params = true; }
   else if (k == "probe_batch_load") {
     // measurement probe: load -> assemble -> store only (every robot reports QC_MAX_ITER); value 0 restores 200
     h->dp.max_iter = value != 0 ? 0 : 200; params = true;

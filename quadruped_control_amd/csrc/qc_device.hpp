@@ -66,7 +66,7 @@ struct DevParams {
   double stance_phase; // gait.cpp:45, default duty of the on-device contact rule
   double tol_d;        // relative multiplier tolerance
   int max_iter;
-  int pad;
+  int clamp_steps;     // clamp steps a fresh robot takes before its first ratio test (one-fill kernels)
 };
 
 // Device code reads the constants through the CONSTANT address space (scalar

@@ -62,6 +62,7 @@ def _inputs(q, n):
 def _controller(q, P, form, tune):
     ctl = q.BalanceController.from_params(P)
     ctl.set_tuning(**FORMS[form])
+    ctl.set_tuning(clamp_steps=1)  # the classic start in every kernel: all instantiations walk the same working-set path
     ctl.set_tuning(**tune)
     return ctl
 
@@ -192,7 +193,7 @@ def test_iteration_cap_and_bad_inputs_agree_across_widths(q, cap):
     b["Rwb"][bad[1::2], 4] = np.inf
     outs = {}
     for g in (4, 2, 1):
-        ctl = q.BalanceController.from_params(P, max_iter=cap).set_tuning(group=g, one_fill=1, race=0)  # one strategy: the widths must agree exactly
+        ctl = q.BalanceController.from_params(P, max_iter=cap).set_tuning(group=g, one_fill=1, race=0, clamp_steps=1)  # one strategy, one start: the widths must agree exactly
         assert ctl.query_launch(n)["lanes_per_robot"] == g
         outs[g] = ctl.control_batch_host(b, want_iterations=True, want_active_set=True)
     ref = outs[4]
@@ -217,6 +218,49 @@ def test_iteration_cap_and_bad_inputs_agree_across_widths(q, cap):
     assert np.all(r["grf_body"][r["status"] != 0] == 0.0) and (r["iterations"] <= cap).all()
     scale = np.maximum(1.0, np.abs(ref["grf_body"][ok]).max(axis=1, keepdims=True))
     assert np.max(np.abs(r["grf_body"][ok] - ref["grf_body"][ok]) / scale) < 1e-8
+
+
+@pytest.mark.parametrize("steps", [0, 2, 3, 6])
+@pytest.mark.parametrize("form,G", [("uniform", 1), ("uniform", 2), ("uniform", 4), ("general", 1), ("general", 2), ("dense", 1)])
+def test_clamp_steps_vs_oracle(q, form, G, steps):
+    """One-fill kernels with several clamp steps before the first ratio test (0 = the kernel's own rule: five on one / two
+    lanes per robot, cold start): a different walk to the same minimiser - oracle parity, KKT certificate, restart from the
+    reported working set in one recalculation, and a warm-started batch is unaffected by the rule."""
+    import torch
+
+    from oracle import c_oracle as O
+    from tests.kkt_batch import assert_kkt
+    from quadruped_control_amd import workloads as W
+
+    P = q.cheetah_params(0.6)
+    n = 8200
+    b = W.config3(n, seed=0x5EED00C1) if steps in (0, 3) else W.config2(n, seed=0x5EED00C2)
+    ref, st, _ = O.control_batch(P, b, threads=8)
+    assert (st == 0).all()
+    ctl = q.BalanceController.from_params(P).set_tuning(group=G, one_fill=1, race=0, clamp_steps=steps, **FORMS[form])
+    info = ctl.query_launch(n)
+    assert (info["form"], info["lanes_per_robot"]) == (FORM_ID[form], G) and info["mode"] >= 1, info
+    d = q.to_device(b)
+    o = ctl.control_batch(d, want_iterations=True, want_active_set=True)
+    torch.cuda.synchronize()
+    assert int((o["status"] != 0).sum()) == 0
+    grf = o["grf_body"].cpu().numpy()
+    assert _relerr(grf, ref) < RTOL
+    assert_kkt(P, b, grf)
+    classic = q.BalanceController.from_params(P).set_tuning(group=G, one_fill=1, race=0, clamp_steps=1, **FORMS[form])
+    c = classic.control_batch(d, want_iterations=True, want_active_set=True)
+    assert _relerr(c["grf_body"].cpu().numpy(), ref) < RTOL
+    it, it_c = o["iterations"].cpu().numpy(), c["iterations"].cpu().numpy()
+    if steps == 0 and G < 4:
+        assert not np.array_equal(it, it_c)  # the rule really is in force ...
+        assert it.mean() < it_c.mean()  # ... and shortens the average walk
+    if steps == 0 and G == 4:
+        assert np.array_equal(it, it_c)  # four lanes per robot keep the classic start
+    again = ctl.control_batch(d, warm=o["active_set"], want_iterations=True)
+    torch.cuda.synchronize()
+    assert int(again["iterations"].max()) == 1 and _relerr(again["grf_body"].cpu().numpy(), ref) < RTOL
+    again_c = classic.control_batch(d, warm=o["active_set"], want_iterations=True)
+    assert torch.equal(again["grf_body"], again_c["grf_body"])
 
 
 @pytest.mark.parametrize("n,strategies", [(4096, 4), (2500, 4), (8192, 2), (6000, 2)])
