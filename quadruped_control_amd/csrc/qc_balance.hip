@@ -506,6 +506,7 @@ QC_DEV void finish_on_four_lanes(const DevParams* __restrict__ Pg, const LaneG& 
   constexpr int GS = LaneG::G, FPL = LaneG::FPL;  // lanes per robot / feet per lane of the layout being left
   const int nb = __builtin_popcountll(bm) / GS;  // running robots
   if (nb == 0) return;
+  QC_CLK_TAIL_BEGIN();
   constexpr int RS = 37;  // record stride in doubles (odd: the four lanes of a group read different banks)
   static_assert(16 * RS <= IN_PLANES * SP, "the re-pack records live in the idle input stock");
   const int rank2 = __builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0)) / GS;
@@ -557,28 +558,29 @@ QC_DEV void finish_on_four_lanes(const DevParams* __restrict__ Pg, const LaneG& 
     L4.have_f = true;
     eqp4.setup(*QC_PARAMS_HERE(Pg), L4.Wr, j4);
   }
+  QC_CLK_TAIL_LOOP();
   if constexpr (STR4 && UNIFORM) {
     // the tail has the registers to keep the recalculation's constants resident, as the mode-2 kernel does
     UConst uc = load_uconst(*QC_PARAMS_HERE(Pg));
     while (__builtin_amdgcn_ballot_w64(busy4) != 0) {
+      QC_CLK(7, 2);
       pin_uconst(uc);
       const bool done = L4.template iterate<Lane4::STEADY>(uc, eqp4, busy4);
       busy4 = busy4 && !done;
     }
   } else if constexpr (STR4) {
     while (__builtin_amdgcn_ballot_w64(busy4) != 0) {
+      QC_CLK(7, 2);
       const bool done = L4.template iterate<Lane4::STEADY>(*QC_PARAMS_HERE(Pg), eqp4, busy4);
       busy4 = busy4 && !done;
     }
   } else {
     while (busy4) busy4 = !L4.template iterate<Lane4::STEADY>(*QC_PARAMS_HERE(Pg), eqp4);
   }
+  QC_CLK_TAIL_END();
   if (g4 < nb) L4.template push_result<SP>(sout, slot4);
 }
 
-// MODE 0: persistent waves (chunks of many fills, lane refill).  MODE 1: the launch gives every wave at most one
-// fill (chunk <= 64 / G).  MODE 2: one fill and the SIMD to itself, recalculation constants resident in VGPRs.
-// RACE (strided 4-lane one-fill kernels): strategies racing per robot, 1, 2 or 4; a wave then holds 16 / RACE robots (see Lane).
 // How many of a cold-started robot's first recalculations are CLAMP steps (project the equality-constrained minimiser
 // of the current working set into the frusta, keep the faces it hits) before the ratio-test steps start.  One is the
 // classic start.  More of them build the working set several faces at a time and cost less than a ratio-test step:
@@ -591,6 +593,9 @@ QC_DEV int clamp_steps_for(CParams& P, const uint32_t* warm) {
   return tuned > 0 ? tuned : ((warm != nullptr || G == 4) ? 1 : 5);
 }
 
+// MODE 0: persistent waves (chunks of many fills, lane refill).  MODE 1: the launch gives every wave at most one
+// fill (chunk <= 64 / G).  MODE 2: one fill and the SIMD to itself, recalculation constants resident in VGPRs.
+// RACE (strided 4-lane one-fill kernels): strategies racing per robot, 1, 2 or 4; a wave then holds 16 / RACE robots (see Lane).
 template <class Eqp, bool KIN, int MIN_WAVES_PER_SIMD, int MODE = 0, int RACE = 1>
 __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const DevParams* __restrict__ Pg, const long n, const BatchIn in,
                                                                          const uint32_t* __restrict__ warm, const BatchOut out, const long chunk,
@@ -747,6 +752,7 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
     if constexpr (Eqp::kRepackTail) {
       unsigned long long bm = __builtin_amdgcn_ballot_w64(busy);
       while (__builtin_popcountll(bm) > 16 * G) {  // more than 16 robots still running
+        QC_CLK(7, 2);
         if (busy) busy = !L.template iterate<LaneT::STEADY>(*QC_PARAMS_HERE(Pg), eqp);
         bm = __builtin_amdgcn_ballot_w64(busy);
       }

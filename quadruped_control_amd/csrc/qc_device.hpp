@@ -29,6 +29,9 @@
 #define QC_CLK(from, to)
 #define QC_CLK_BEGIN()
 #define QC_CLK_END(last)
+#define QC_CLK_TAIL_BEGIN()  // harness: the 4-lane tail of a one / two lanes-per-robot wave is clocked into its own slots
+#define QC_CLK_TAIL_LOOP()
+#define QC_CLK_TAIL_END()
 #define QC_CLK_PIN(arr)  // harness: pins the values of `arr` at this point so the scheduler cannot move a phase across its marker
 #endif
 

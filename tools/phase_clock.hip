@@ -5,22 +5,36 @@
 //   6 forces + gradient                 7 ratio test, multipliers, state update    8 final flush (output transform + store)
 //   9 empty (marker cost, counted twice per iterate)
 //   10 iterate calls                    11 s_memrealtime ticks (100 MHz) start -> end, 12 s_memtime ticks start -> end
+//   16 + k: phase k of the recalculations of the 4-lane tail (one / two lanes-per-robot kernels), 26 their count; 1 = the re-pack
 // Each marker costs one s_memtime + s_waitcnt (~50-100 cycles): compare phases, do not read totals as product time.
 #include <hip/hip_runtime.h>
-__device__ unsigned long long qc_clk_global[16];
-__shared__ unsigned long long qc_clk_lds[16];
+__device__ unsigned long long qc_clk_global[32];
+__shared__ unsigned long long qc_clk_lds[32];
+__shared__ int qc_clk_off;  // 0, or 16 while the 4-lane tail runs (slots 16 + phase)
 #define QC_CLK_ELECT() (threadIdx.x < 64 && __lane_id() == (unsigned)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true)))  // wave 0 of the workgroup
 #define QC_CLK(from, to)                                                               \
   do {                                                                                 \
     const unsigned long long t_ = __builtin_readcyclecounter();                        \
     if (QC_CLK_ELECT()) {                                                              \
-      atomicAdd(&qc_clk_lds[from], t_);                                                \
-      atomicAdd(&qc_clk_lds[to], 0ull - t_);                                           \
-      if ((to) == 2) atomicAdd(&qc_clk_lds[10], 1ull);                                 \
+      atomicAdd(&qc_clk_lds[(from) + qc_clk_off], t_);                                 \
+      atomicAdd(&qc_clk_lds[(to) + qc_clk_off], 0ull - t_);                            \
+      if ((to) == 2) atomicAdd(&qc_clk_lds[10 + qc_clk_off], 1ull);                    \
     }                                                                                  \
   } while (0)
+#define QC_CLK_X(from, to)  /* absolute slots */                                       \
+  do {                                                                                 \
+    const unsigned long long t_ = __builtin_readcyclecounter();                        \
+    if (QC_CLK_ELECT()) {                                                              \
+      atomicAdd(&qc_clk_lds[from], t_);                                                \
+      atomicAdd(&qc_clk_lds[to], 0ull - t_);                                           \
+    }                                                                                  \
+  } while (0)
+#define QC_CLK_TAIL_BEGIN() do { QC_CLK_X(7, 1); } while (0)                 /* slot 1: the re-pack */
+#define QC_CLK_TAIL_LOOP() do { QC_CLK_X(1, 23); qc_clk_off = 16; } while (0)
+#define QC_CLK_TAIL_END() do { qc_clk_off = 0; QC_CLK_X(23, 7); } while (0)
 #define QC_CLK_BEGIN()                                                                 \
-  if (threadIdx.x < 16) qc_clk_lds[threadIdx.x] = 0;                                   \
+  if (threadIdx.x < 32) qc_clk_lds[threadIdx.x] = 0;                                   \
+  if (threadIdx.x == 0) qc_clk_off = 0;                                                \
   __syncthreads();                                                                     \
   if (threadIdx.x == 0) {                                                              \
     qc_clk_lds[0] = 0ull - __builtin_readcyclecounter();                               \
@@ -38,7 +52,7 @@ __shared__ unsigned long long qc_clk_lds[16];
       qc_clk_lds[11] += __builtin_amdgcn_s_memrealtime();                              \
     }                                                                                  \
     __syncthreads();                                                                   \
-    if (blockIdx.x == QC_CLK_BLOCK && threadIdx.x < 16) atomicAdd(&qc_clk_global[threadIdx.x], qc_clk_lds[threadIdx.x]); \
+    if (blockIdx.x == QC_CLK_BLOCK && threadIdx.x < 32) atomicAdd(&qc_clk_global[threadIdx.x], qc_clk_lds[threadIdx.x]); \
   } while (0)
 #define QC_CLK_PIN(arr)                                                               \
   do {                                                                                 \
@@ -49,10 +63,10 @@ __shared__ unsigned long long qc_clk_lds[16];
 #endif
 #include "../quadruped_control_amd/csrc/qc_balance.hip"
 
-extern "C" int qc_clk_read(unsigned long long* out16, int reset) {
-  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(qc_clk_global), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+extern "C" int qc_clk_read(unsigned long long* out32, int reset) {
+  if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(qc_clk_global), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
   if (reset) {
-    unsigned long long z[16] = {0};
+    unsigned long long z[32] = {0};
     if (hipMemcpyToSymbol(HIP_SYMBOL(qc_clk_global), z, sizeof(z)) != hipSuccess) return -1;
   }
   return 0;

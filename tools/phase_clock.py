@@ -24,7 +24,7 @@ b = q.to_device({2: W.config2, 3: W.config3}[cfg](n))
 launch, out = ctl.plan_batch(b)
 NAMES = ["first restock", "loop/refill/push", "coef + local M", "group reduce", "LDL^T", "tri solves", "forces+grad",
          "ratio/mult/update", "final flush", "(one marker)"]
-buf = (C.c_ulonglong * 16)()
+buf = (C.c_ulonglong * 32)()
 for _ in range(3):
     launch()
 torch.cuda.synchronize()
@@ -35,11 +35,18 @@ for _ in range(reps):
 torch.cuda.synchronize()
 lib.qc_clk_read(buf, 1)
 v = np.array(list(buf), dtype=np.uint64).astype(np.int64) / reps
+if os.environ.get("QC_CLK_ALL"):  # library built with -DQC_CLK_BLOCK=blockIdx.x: every workgroup adds its clocks; print the average
+    v = v / ctl.query_launch(n)["blocks"]
 its = v[10]
 print("kernel %s, n=%d: block 0 made %.1f iterate calls per launch; %.0f cycles = %.2f us (s_memtime %.0f MHz)" %
       (ctl.kernel_name, n, its, v[12], v[11] / 100.0, v[12] / (v[11] / 100.0)))
 for k, nm in enumerate(NAMES):
     per = v[k] / its if 2 <= k <= 7 or k == 9 else float("nan")
     print("  %-20s %9.0f cycles total  %8.0f per iterate" % (nm, v[k], per))
+if v[26] > 0:
+    print("  4-lane tail: %.1f iterate calls per launch, re-pack %.0f cycles" % (v[26], v[1]))
+    for k in range(2, 8):
+        print("    %-18s %9.0f cycles total  %8.0f per iterate" % (NAMES[k], v[16 + k], v[16 + k] / v[26]))
+    print("    tail total %.0f cycles (+ re-pack) of %.0f" % (v[18:24].sum(), v[12]))
 mk = v[9] / its
 print("  sum of iterate phases per call: %.0f cycles, of which markers ~%.0f (8 x %.0f)" % ((v[2:8].sum() + v[9]) / its, 8 * mk, mk))
