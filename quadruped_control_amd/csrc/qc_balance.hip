@@ -492,93 +492,157 @@ QC_DEV void flush_out(const DevParams* __restrict__ Pg, const BatchIn& in, const
   }
 }
 
+// record of one running robot in the re-pack area (37 doubles: odd, so the four lanes of a group read different
+// banks): 0-5 b, 6 idx, 7 {iters, output slot, stance}, 8-19 r, 20-31 f, 32-35 face code per foot
+constexpr int REPACK_RS = 37;
+template <class LaneX>
+QC_DEV void repack_write(const LaneX& L, double* __restrict__ rec, int slot, int member) {
+  constexpr int FPL = LaneX::FPL;
+  if (member == 0) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) rec[k] = L.Wr.b[k];
+    rec[6] = __longlong_as_double(L.idx);
+    rec[7] = __longlong_as_double((long long)(((unsigned long long)(uint32_t)((L.iters << 8) | slot) << 32) | L.stance));
+  }
+#pragma unroll
+  for (int i = 0; i < FPL; i++) {
+    const int ft = L.foot0 + i;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      rec[8 + 3 * ft + k] = L.Wr.r[i][k];
+      rec[20 + 3 * ft + k] = L.f[3 * i + k];
+    }
+    rec[32 + ft] = __longlong_as_double((long long)encode_foot(L.C.sx[i], L.C.sy[i], L.C.sz[i]));
+  }
+}
+// ... and into member j4 of a 4-lane group; returns the robot's slot in the output stock
+template <class Lane4X, class Eqp4X>
+QC_DEV int repack_read(const DevParams* __restrict__ Pg, Lane4X& L4, Eqp4X& eqp4, const double* __restrict__ rec, int j4) {
+#pragma unroll
+  for (int k = 0; k < 6; k++) L4.Wr.b[k] = rec[k];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    L4.Wr.r[0][k] = rec[8 + 3 * j4 + k];
+    L4.f[k] = rec[20 + 3 * j4 + k];
+  }
+  const uint32_t fw = (uint32_t)__double_as_longlong(rec[32 + j4]);
+  L4.C.sx[0] = dec2(fw); L4.C.sy[0] = dec2(fw >> 2); L4.C.sz[0] = dec2(fw >> 4);
+  L4.idx = __double_as_longlong(rec[6]);
+  const unsigned long long fl = (unsigned long long)__double_as_longlong(rec[7]);
+  L4.stance = (uint32_t)fl;
+  L4.iters = (int)(fl >> 40);
+  L4.foot0 = j4;
+  L4.status = QC_MAX_ITER;
+  L4.have_f = true;
+  eqp4.setup(*QC_PARAMS_HERE(Pg), L4.Wr, j4);
+  return (int)((fl >> 32) & 0xFFu);
+}
+
 // One or two lanes per robot: once at most 16 robots of a wave are still running they fit a 4-lanes-per-robot layout,
 // whose recalculation is much shorter (487 instructions against 730 at two lanes and ~1170 at one) - and the wave
 // waits for exactly these stragglers.  The running robots are re-packed through the (now idle) input stock and finish
 // on the G = 4 body; `slot` is where the robot's result goes in the output stock.  `bm` = ballot(busy), at most
 // 16 robots.
+// Two stages (strided layout): while more than 8 robots run, the classic body.  Then the survivors are re-packed once
+// more, each into TWO groups 8 lanes apart that continue with different drop rules - most negative multiplier / all
+// negative multipliers - and the first at the KKT point wins (the racing strategies of the mode-2 kernel, applied to
+// the robots every other lane of the wave is waiting for).  Forking after ~6 recalculations still shortens the
+// slowest robot's chain: 20 -> 16 on config 3's 16 384 first robots, mean of the per-wave maximum 11.5 -> 10.6
+// (oracle/prototypes/proto_tail_fork.py); clamp-step variants add nothing at that point.
 template <bool KIN, bool UNIFORM, int SP, class LaneG>
 QC_DEV void finish_on_four_lanes(const DevParams* __restrict__ Pg, const LaneG& L, bool busy, unsigned long long bm, int slot, int member, int lane,
-                                 double* __restrict__ sin, double* __restrict__ sout) {
+                                 double* __restrict__ sin, double* __restrict__ sout, const bool cold) {
   using Eqp4 = EqpDiagW<UNIFORM, 4, !QC_NO_STRIDED>;
   using Lane4 = Lane<Eqp4, KIN>;
+  using LaneR = Lane<Eqp4, KIN, true>;  // with a per-lane drop rule
   constexpr bool STR4 = Eqp4::kStrided;
-  constexpr int GS = LaneG::G, FPL = LaneG::FPL;  // lanes per robot / feet per lane of the layout being left
+  constexpr int GS = LaneG::G;  // lanes per robot of the layout being left
+  constexpr int RS = REPACK_RS;
   const int nb = __builtin_popcountll(bm) / GS;  // running robots
   if (nb == 0) return;
   QC_CLK_TAIL_BEGIN();
-  constexpr int RS = 37;  // record stride in doubles (odd: the four lanes of a group read different banks)
   static_assert(16 * RS <= IN_PLANES * SP, "the re-pack records live in the idle input stock");
   const int rank2 = __builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0)) / GS;
   __syncthreads();  // nobody reads the input stock any more
-#define QC_REC(rank, f) sin[(rank) * RS + (f)]
-  if (busy) {
-    if (member == 0) {
-#pragma unroll
-      for (int k = 0; k < 6; k++) QC_REC(rank2, k) = L.Wr.b[k];
-      QC_REC(rank2, 6) = __longlong_as_double(L.idx);
-      QC_REC(rank2, 7) = __longlong_as_double((long long)(((unsigned long long)(uint32_t)((L.iters << 8) | slot) << 32) | L.stance));
-    }
-#pragma unroll
-    for (int i = 0; i < FPL; i++) {
-      const int ft = FPL * member + i;
-#pragma unroll
-      for (int k = 0; k < 3; k++) {
-        QC_REC(rank2, 8 + 3 * ft + k) = L.Wr.r[i][k];
-        QC_REC(rank2, 20 + 3 * ft + k) = L.f[3 * i + k];
-      }
-      QC_REC(rank2, 32 + ft) = __longlong_as_double((long long)encode_foot(L.C.sx[i], L.C.sy[i], L.C.sz[i]));
-    }
-  }
+  if (busy) repack_write(L, sin + rank2 * RS, slot, member);
   __syncthreads();
-  Lane4 L4;
-  Eqp4 eqp4(nullptr);
   const int g4 = lane_group<4, STR4>(lane), j4 = lane_member<4, STR4>(lane);
-  bool busy4 = g4 < nb;
-  int slot4 = 0;
-  {  // groups beyond the running robots shadow record 0: the strided layout keeps every lane in the loop (MFMA)
-    const int r4 = busy4 || !STR4 ? g4 : 0;
-#pragma unroll
-    for (int k = 0; k < 6; k++) L4.Wr.b[k] = QC_REC(r4, k);
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      L4.Wr.r[0][k] = QC_REC(r4, 8 + 3 * j4 + k);
-      L4.f[k] = QC_REC(r4, 20 + 3 * j4 + k);
-    }
-    const uint32_t fw = (uint32_t)__double_as_longlong(QC_REC(r4, 32 + j4));
-    L4.C.sx[0] = dec2(fw); L4.C.sy[0] = dec2(fw >> 2); L4.C.sz[0] = dec2(fw >> 4);
-    L4.idx = __double_as_longlong(QC_REC(r4, 6));
-    const unsigned long long fl = (unsigned long long)__double_as_longlong(QC_REC(r4, 7));
-#undef QC_REC
-    L4.stance = (uint32_t)fl;
-    slot4 = (int)((fl >> 32) & 0xFFu);
-    L4.iters = (int)(fl >> 40);
-    L4.foot0 = j4;
-    L4.status = QC_MAX_ITER;
-    L4.have_f = true;
-    eqp4.setup(*QC_PARAMS_HERE(Pg), L4.Wr, j4);
-  }
+  // (a warm-started robot that is not done after its first recalculation is a face or two away: nothing to race for;
+  // measured neutral to +0.5 us on config 4's tick, tools/tail_race_scan.py)
+  const bool race = STR4 && cold && QC_PARAMS_HERE(Pg)->tail_race != 0;
+  int nrun = nb;  // robots the race stage starts with (the first re-pack's records if the classic stage is skipped)
   QC_CLK_TAIL_LOOP();
-  if constexpr (STR4 && UNIFORM) {
-    // the tail has the registers to keep the recalculation's constants resident, as the mode-2 kernel does
-    UConst uc = load_uconst(*QC_PARAMS_HERE(Pg));
-    while (__builtin_amdgcn_ballot_w64(busy4) != 0) {
-      QC_CLK(7, 2);
-      pin_uconst(uc);
-      const bool done = L4.template iterate<Lane4::STEADY>(uc, eqp4, busy4);
-      busy4 = busy4 && !done;
+  if (!race || nb > 8) {
+    Lane4 L4;
+    Eqp4 eqp4(nullptr);
+    bool busy4 = g4 < nb;
+    // groups beyond the running robots shadow record 0: the strided layout keeps every lane in the loop (MFMA)
+    const int slot4 = repack_read(Pg, L4, eqp4, sin + (busy4 || !STR4 ? g4 : 0) * RS, j4);
+    const int stop = race ? 8 : 0;
+    if constexpr (STR4 && UNIFORM) {
+      // the tail has the registers to keep the recalculation's constants resident, as the mode-2 kernel does
+      UConst uc = load_uconst(*QC_PARAMS_HERE(Pg));
+      while (__builtin_popcountll(__builtin_amdgcn_ballot_w64(busy4) & 0xFFFFull) > stop) {
+        QC_CLK(7, 2);
+        pin_uconst(uc);
+        const bool done = L4.template iterate<Lane4::STEADY>(uc, eqp4, busy4);
+        busy4 = busy4 && !done;
+      }
+    } else if constexpr (STR4) {
+      while (__builtin_popcountll(__builtin_amdgcn_ballot_w64(busy4) & 0xFFFFull) > stop) {
+        QC_CLK(7, 2);
+        const bool done = L4.template iterate<Lane4::STEADY>(*QC_PARAMS_HERE(Pg), eqp4, busy4);
+        busy4 = busy4 && !done;
+      }
+    } else {
+      while (busy4) busy4 = !L4.template iterate<Lane4::STEADY>(*QC_PARAMS_HERE(Pg), eqp4);
     }
-  } else if constexpr (STR4) {
-    while (__builtin_amdgcn_ballot_w64(busy4) != 0) {
-      QC_CLK(7, 2);
-      const bool done = L4.template iterate<Lane4::STEADY>(*QC_PARAMS_HERE(Pg), eqp4, busy4);
-      busy4 = busy4 && !done;
+    if (g4 < nb && !busy4) L4.template push_result<SP>(sout, slot4);
+    const unsigned run16 = (unsigned)(__builtin_amdgcn_ballot_w64(busy4) & 0xFFFFull);  // (member 0 of the strided groups = lanes 0-15)
+    nrun = __builtin_popcount(run16);
+    if (nrun == 0) {
+      QC_CLK_TAIL_END();
+      return;
     }
-  } else {
-    while (busy4) busy4 = !L4.template iterate<Lane4::STEADY>(*QC_PARAMS_HERE(Pg), eqp4);
+    // second re-pack: the <= 8 survivors
+    const int rank = __builtin_popcount(run16 & ((1u << g4) - 1u));
+    __syncthreads();
+    if (busy4) repack_write(L4, sin + rank * RS, slot4, j4);
+    __syncthreads();
   }
-  QC_CLK_TAIL_END();
-  if (g4 < nb) L4.template push_result<SP>(sout, slot4);
+  if constexpr (STR4) {
+    LaneR LR;
+    Eqp4 eqpR(nullptr);
+    const int r = g4 & 7, sid = g4 >> 3;  // robot, strategy of this group
+    bool busyR = r < nrun;
+    const int slotR = repack_read(Pg, LR, eqpR, sin + (busyR ? r : 0) * RS, j4);
+    LR.drop_all = sid == 1;
+    unsigned solved_mask = 0;  // strategies of this lane's robot that have reached the KKT point
+    auto after = [&](bool done) {
+      const int mine = (busyR && done && LR.status == QC_SOLVED) ? (1 << sid) : 0;
+      const int m = mine | __builtin_amdgcn_update_dpp(0, mine, 0x120 + 8, 0xF, 0xF, true);  // row_ror 8: the partner group
+      solved_mask |= (unsigned)m;
+      busyR = busyR && !done && solved_mask == 0;
+    };
+    if constexpr (UNIFORM) {
+      UConst uc = load_uconst(*QC_PARAMS_HERE(Pg));
+      while (__builtin_amdgcn_ballot_w64(busyR) != 0) {
+        QC_CLK(7, 2);
+        pin_uconst(uc);
+        after(LR.template iterate<LaneR::STEADY>(uc, eqpR, busyR));
+      }
+    } else {
+      while (__builtin_amdgcn_ballot_w64(busyR) != 0) {
+        QC_CLK(7, 2);
+        after(LR.template iterate<LaneR::STEADY>(*QC_PARAMS_HERE(Pg), eqpR, busyR));
+      }
+    }
+    QC_CLK_TAIL_END();
+    // the winner - the lower-numbered strategy if both got there in the same recalculation, strategy 0 with whatever
+    // status it has if none did - parks the result
+    const int win = solved_mask ? __builtin_ctz(solved_mask) : 0;
+    if (r < nrun && sid == win) LR.template push_result<SP>(sout, slotR);
+  }
 }
 
 // How many of a cold-started robot's first recalculations are CLAMP steps (project the equality-constrained minimiser
@@ -757,7 +821,7 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
         bm = __builtin_amdgcn_ballot_w64(busy);
       }
       if (!busy && mine) L.template push_result<SP>(sout, grp);  // finished in the two-lane layout
-      finish_on_four_lanes<KIN, Eqp::kUniform, SP>(Pg, L, busy, bm, grp, member, lane, sin, sout);
+      finish_on_four_lanes<KIN, Eqp::kUniform, SP>(Pg, L, busy, bm, grp, member, lane, sin, sout, warm == nullptr);
     } else {
       while (busy) {
         if constexpr (RESIDENT) {
@@ -1253,6 +1317,7 @@ int qc_create(const qc_params* p, int device, qc_handle** out) {
   d.tol_d = 1e-14;
   d.max_iter = p->max_iter > 0 ? p->max_iter : 200;
   d.clamp_steps = 0;  // 0: per kernel (clamp_steps_for)
+  d.tail_race = 1;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete h; return fail(QC_ERR_HIP, "qc_create: hipGetDeviceProperties failed"); }
   h->cus = prop.multiProcessorCount;
@@ -1286,7 +1351,11 @@ int qc_set_tuning(qc_handle* h, const char* key, double value) {
   } else if (k == "one_fill") h->one_fill_override = value < 0 ? -1 : (value != 0 ? 1 : 0);
   else if (k == "chunk") h->chunk_override = value > 0 ? (long)value : 0;
   else if (k == "wave_slots") h->wave_slots_override = value > 0 ? (int)value : 0;
-  else if (k == "race") h->race_override = value < 0 ? -1 : (int)value;
+  else if (k == "race") {  // (0 / 1 also switch the race in the 4-lane tail of the wider kernels off)
+    h->race_override = value < 0 ? -1 : (int)value;
+    h->dp.tail_race = (value < 0 || value >= 2) ? 1 : 0;
+    params = true;
+  }
   else if (k == "min_waves") h->min_waves = value > 2 ? (int)value : 2;
   else if (k == "refill_t") h->refill_t = value > 0 ? (int)value : 16;
   else if (k == "rounds_cold") h->rounds_cold = value;

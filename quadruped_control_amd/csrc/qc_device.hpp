@@ -70,6 +70,8 @@ struct DevParams {
   double tol_d;        // relative multiplier tolerance
   int max_iter;
   int clamp_steps;     // clamp steps a fresh robot takes before its first ratio test (one-fill kernels)
+  int tail_race;       // the 4-lane tail races two drop rules on its last <= 8 robots
+  int pad;
 };
 
 // Device code reads the constants through the CONSTANT address space (scalar

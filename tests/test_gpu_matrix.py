@@ -62,7 +62,7 @@ def _inputs(q, n):
 def _controller(q, P, form, tune):
     ctl = q.BalanceController.from_params(P)
     ctl.set_tuning(**FORMS[form])
-    ctl.set_tuning(clamp_steps=1)  # the classic start in every kernel: all instantiations walk the same working-set path
+    ctl.set_tuning(clamp_steps=1, race=0)  # the classic start and drop rule in every kernel: all instantiations walk the same working-set path
     ctl.set_tuning(**tune)
     return ctl
 
@@ -261,6 +261,51 @@ def test_clamp_steps_vs_oracle(q, form, G, steps):
     assert int(again["iterations"].max()) == 1 and _relerr(again["grf_body"].cpu().numpy(), ref) < RTOL
     again_c = classic.control_batch(d, warm=o["active_set"], want_iterations=True)
     assert torch.equal(again["grf_body"], again_c["grf_body"])
+
+
+@pytest.mark.parametrize("start", ["cold", "warm"])
+@pytest.mark.parametrize("form,G,n", [("uniform", 1, 65536), ("uniform", 2, 20000), ("general", 1, 30011), ("general", 2, 8200)])
+def test_tail_race_vs_oracle(q, form, G, n, start):
+    """One / two lanes per robot with the product's defaults: the last <= 8 running robots of a wave race two drop
+    rules on the 4-lane body.  Same minimiser as the oracle, KKT-certified, never more recalculations than with the race
+    switched off, fewer for the slowest robot of a cold batch, restart from the reported working set in one."""
+    import torch
+
+    from oracle import c_oracle as O
+    from tests.kkt_batch import assert_kkt
+    from quadruped_control_amd import workloads as W
+
+    P = q.cheetah_params(0.6)
+    if start == "warm":
+        prev, b = W.config4(n, seed=0x5EED00D1)
+    else:
+        b = W.config3(n, seed=0x5EED00D2)
+    ref, st, _ = O.control_batch(P, b, threads=8)
+    assert (st == 0).all()
+    d = q.to_device(b)
+    warm = None
+    if start == "warm":
+        warm = q.BalanceController.from_params(P).control_batch(q.to_device(prev), want_active_set=True)["active_set"]
+    race = q.BalanceController.from_params(P).set_tuning(group=G, one_fill=1, **FORMS[form])
+    solo = q.BalanceController.from_params(P).set_tuning(group=G, one_fill=1, race=0, **FORMS[form])
+    assert race.query_launch(n)["lanes_per_robot"] == G
+    o = race.control_batch(d, warm=warm, want_iterations=True, want_active_set=True)
+    s_ = solo.control_batch(d, warm=warm, want_iterations=True)
+    torch.cuda.synchronize()
+    assert int((o["status"] != 0).sum()) == 0 and int((s_["status"] != 0).sum()) == 0
+    grf = o["grf_body"].cpu().numpy()
+    assert _relerr(grf, ref) < RTOL and _relerr(s_["grf_body"].cpu().numpy(), ref) < RTOL
+    assert np.all(grf[np.repeat(b["stance"] == 0, 3, axis=1)] == 0.0)
+    assert_kkt(P, b, grf)
+    it_r, it_s = o["iterations"].cpu().numpy(), s_["iterations"].cpu().numpy()
+    assert (it_r <= it_s).all() and it_r.min() >= 1
+    if start == "warm":
+        assert np.array_equal(it_r, it_s)  # warm-started batches keep the classic tail
+    if start == "cold":
+        assert (it_r < it_s).any() and it_r.max() <= it_s.max()  # the race is really in force
+    again = solo.control_batch(d, warm=o["active_set"], want_iterations=True)
+    torch.cuda.synchronize()
+    assert int(again["iterations"].max()) == 1 and _relerr(again["grf_body"].cpu().numpy(), ref) < RTOL
 
 
 @pytest.mark.parametrize("n,strategies", [(4096, 4), (2500, 4), (8192, 2), (6000, 2)])
