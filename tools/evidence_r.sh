@@ -18,6 +18,7 @@ timeout 600 python tools/tick_scan.py 2>&1 | grep -v amdgpu.ids > $OUT/tick_scan
 timeout 300 python tools/iter_scan.py 4096 2 2>&1 | grep -v amdgpu.ids > $OUT/iter_scan_cfg2.log
 timeout 300 python tools/race_scan.py 2>&1 | grep -v amdgpu.ids > $OUT/race_scan.log
 { timeout 600 python tools/clamp_scan_seeds.py 1 2 3 4 5 6 8 16; timeout 300 python tools/clamp_scan.py 1 2 4 5 6; } 2>&1 | grep -v amdgpu.ids > $OUT/clamp_scan.log
+timeout 600 python tools/tail_race_scan.py 2>&1 | grep -v amdgpu.ids > $OUT/tail_race_scan.log
 timeout 120 python tools/sort_stat.py 2>&1 | grep -v amdgpu.ids > $OUT/sort_stat.log
 if [ -f tools/_build/libqc_balance_clk_all.so ]; then  # phase clocks averaged over every workgroup (tools/phase_clock.hip, -DQC_CLK_BLOCK=blockIdx.x)
   for a in "4096 2 4" "4096 2 4 0 race=0" "65536 3 1" "262144 3 1" "32768 3 2"; do
