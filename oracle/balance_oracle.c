@@ -195,6 +195,43 @@ static int lin_solve(double* M, double* rhs, int n) {
   return 0;
 }
 
+/* The same elimination in long double (x87 extended precision here): used ONCE per QP, to recompute the accepted point.
+ * With W = w I and w <= 2e-7 the KKT matrix has a condition number of 1e9 and more, and the double-precision solve
+ * leaves up to 3e-4 N on the weakly determined force components - the NNLS restatement (oracle/numpy_restatement.py)
+ * put the GPU path's 6x6 form closer to the minimiser than this oracle on such problems (profiles/r02_stress_extended.log).
+ * Decisions (ratio tests, multiplier signs) stay in double; only the reported point is refined. */
+static int lin_solve_ld(const double* M0, const double* rhs0, int n, double* x) {
+  long double M[KMAX * KMAX], rhs[KMAX];
+  for (int r = 0; r < n; r++) {
+    for (int k = 0; k < n; k++) M[r * KMAX + k] = M0[r * KMAX + k];
+    rhs[r] = rhs0[r];
+  }
+  for (int c = 0; c < n; c++) {
+    int p = c;
+    long double best = fabsl(M[c * KMAX + c]);
+    for (int r = c + 1; r < n; r++)
+      if (fabsl(M[r * KMAX + c]) > best) { best = fabsl(M[r * KMAX + c]); p = r; }
+    if (best < 1e-300L) return 1;
+    if (p != c) {
+      for (int k = 0; k < n; k++) { long double t = M[c * KMAX + k]; M[c * KMAX + k] = M[p * KMAX + k]; M[p * KMAX + k] = t; }
+      long double t = rhs[c]; rhs[c] = rhs[p]; rhs[p] = t;
+    }
+    for (int r = c + 1; r < n; r++) {
+      long double m = M[r * KMAX + c] / M[c * KMAX + c];
+      if (m == 0.0L) continue;
+      for (int k = c; k < n; k++) M[r * KMAX + k] -= m * M[c * KMAX + k];
+      rhs[r] -= m * rhs[c];
+    }
+  }
+  for (int r = n - 1; r >= 0; r--) {
+    long double s = rhs[r];
+    for (int k = r + 1; k < n; k++) s -= M[r * KMAX + k] * rhs[k];
+    rhs[r] = s / M[r * KMAX + r];
+  }
+  for (int r = 0; r < n; r++) x[r] = (double)rhs[r];
+  return 0;
+}
+
 /* is row `a` linearly independent of the rows listed in idx[0..m)? */
 static int independent(const double* C, const int* idx, int m, const double* a) {
   double basis[NV][NV];
@@ -277,6 +314,9 @@ int oracle_qp_solve(const double* H, const double* g, const double* C, const dou
       for (int k = 0; k < NV; k++) { M[(NV + t) * KMAX + k] = C[r * NV + k]; M[k * KMAX + NV + t] = C[r * NV + k]; }
       rhs[NV + t] = (ws[r] == -1) ? lb[r] : ub[r];
     }
+    double M0[KMAX * KMAX], rhs0[KMAX];  /* (lin_solve works in place: kept for the refined solve of the accepted point) */
+    memcpy(M0, M, sizeof(M));
+    memcpy(rhs0, rhs, sizeof(rhs));
     if (lin_solve(M, rhs, n)) return ORACLE_NOT_PD;
     double d[NV];
     for (int k = 0; k < NV; k++) d[k] = rhs[k] - f[k];
@@ -328,6 +368,9 @@ int oracle_qp_solve(const double* H, const double* g, const double* C, const dou
       if (viol > 1e-15 * gs && (bland ? (worst < 0 || idx[t] < idx[worst]) : viol > wv)) { wv = viol; worst = t; }
     }
     if (worst < 0) {
+      double xr[KMAX];
+      if (lin_solve_ld(M0, rhs0, n, xr) == 0)
+        for (int k = 0; k < NV; k++) f[k] = xr[k];
       /* a checker must not certify an infeasible point: nearly parallel rows (mu -> 0) can defeat the
        * dependent-row logic above; report failure instead of a wrong ORACLE_OK */
       double fs = 1.0; /* scale of the solution: the KKT solves leave ~cond*eps*|f| on the pinned rows */
