@@ -17,7 +17,7 @@ def timeit(ctl, b, warm=None, reps=20):
     assert int((out["status"] != 0).sum()) == 0
     return e0.elapsed_time(e1) / reps * 1e3, int(out["iterations"].max())
 SEEDS = [0x5EED0003 + 0x1000 * k for k in range(8)]
-for n in (32768, 65536, 131072, 262144, 1048576):
+for n in (6144, 8192, 12288, 16384, 32768, 65536, 131072, 262144, 1048576):
     rows = {"off": [], "on": []}
     for seed in SEEDS:
         b = WD.config3(n, seed=seed)
