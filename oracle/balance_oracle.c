@@ -200,6 +200,10 @@ static int lin_solve(double* M, double* rhs, int n) {
  * leaves up to 3e-4 N on the weakly determined force components - the NNLS restatement (oracle/numpy_restatement.py)
  * put the GPU path's 6x6 form closer to the minimiser than this oracle on such problems (profiles/r02_stress_extended.log).
  * Decisions (ratio tests, multiplier signs) stay in double; only the reported point is refined. */
+static int g_refine = 1;
+/* 0: skip the long-double recomputation (bench.py times the port that way: the refinement is checker accuracy, not part of
+ * the reference path, and x87 arithmetic would make the CPU baseline 35 % slower than the algorithm is) */
+void oracle_set_refine(int on) { g_refine = on; }
 static int lin_solve_ld(const double* M0, const double* rhs0, int n, double* x) {
   long double M[KMAX * KMAX], rhs[KMAX];
   for (int r = 0; r < n; r++) {
@@ -369,7 +373,7 @@ int oracle_qp_solve(const double* H, const double* g, const double* C, const dou
     }
     if (worst < 0) {
       double xr[KMAX];
-      if (lin_solve_ld(M0, rhs0, n, xr) == 0)
+      if (g_refine && lin_solve_ld(M0, rhs0, n, xr) == 0)
         for (int k = 0; k < NV; k++) f[k] = xr[k];
       /* a checker must not certify an infeasible point: nearly parallel rows (mu -> 0) can defeat the
        * dependent-row logic above; report failure instead of a wrong ORACLE_OK */

@@ -64,6 +64,8 @@ int oracle_control(const oracle_params* P, const double* Rwb, const double* Rwb_
                    double* grf_body, double* f_world, int* iters);
 
 /* n robots, arrays as in include/qc_balance.h (host memory). threads<=1: serial. */
+/* checker accuracy switch: 1 (default) = the accepted point of every QP is recomputed in long double */
+void oracle_set_refine(int on);
 void oracle_control_batch(const oracle_params* P, long n, const double* Rwb, const double* Rwb_d,
                           const double* x, const double* xdot, const double* w, const double* x_d,
                           const double* xdot_d, const double* w_d, const double* feet,

@@ -51,6 +51,11 @@ def lib():
     return _lib
 
 
+def set_refine(on):
+    """1 (default): the C oracle recomputes every accepted point in long double; 0: plain double (timing runs)."""
+    lib().oracle_set_refine(C.c_int(1 if on else 0))
+
+
 def make_params(P, max_iter=200):
     p = OracleParams()
     p.mu, p.mass, p.fzmin, p.fzmax = P["mu"], P["mass"], P["fzmin"], P["fzmax"]
