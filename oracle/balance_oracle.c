@@ -264,6 +264,21 @@ static int independent(const double* C, const int* idx, int m, const double* a) 
   return 0;
 }
 
+/* KKT system of the equality-constrained subproblem on the working set idx[0..m) */
+static void build_kkt(const double* H, const double* g, const double* C, const double* lb, const double* ub, const int* ws, const int* idx, int m,
+                      double* M, double* rhs) {
+  memset(M, 0, sizeof(double) * KMAX * KMAX);
+  for (int i = 0; i < NV; i++) {
+    for (int j = 0; j < NV; j++) M[i * KMAX + j] = H[i * NV + j];
+    rhs[i] = -g[i];
+  }
+  for (int t = 0; t < m; t++) {
+    int r = idx[t];
+    for (int k = 0; k < NV; k++) { M[(NV + t) * KMAX + k] = C[r * NV + k]; M[k * KMAX + NV + t] = C[r * NV + k]; }
+    rhs[NV + t] = (ws[r] == -1) ? lb[r] : ub[r];
+  }
+}
+
 int oracle_qp_solve(const double* H, const double* g, const double* C, const double* lb,
                     const double* ub, int max_iter, double* f, double* lam_out, int* iters_out) {
   /* Feasible start: the reference's bounds always admit f_i = (0,0,lb of the
@@ -308,19 +323,7 @@ int oracle_qp_solve(const double* H, const double* g, const double* C, const dou
     /* KKT system of the equality-constrained subproblem */
     double M[KMAX * KMAX], rhs[KMAX];
     int n = NV + m;
-    memset(M, 0, sizeof(M));
-    for (int i = 0; i < NV; i++) {
-      for (int j = 0; j < NV; j++) M[i * KMAX + j] = H[i * NV + j];
-      rhs[i] = -g[i];
-    }
-    for (int t = 0; t < m; t++) {
-      int r = idx[t];
-      for (int k = 0; k < NV; k++) { M[(NV + t) * KMAX + k] = C[r * NV + k]; M[k * KMAX + NV + t] = C[r * NV + k]; }
-      rhs[NV + t] = (ws[r] == -1) ? lb[r] : ub[r];
-    }
-    double M0[KMAX * KMAX], rhs0[KMAX];  /* (lin_solve works in place: kept for the refined solve of the accepted point) */
-    memcpy(M0, M, sizeof(M));
-    memcpy(rhs0, rhs, sizeof(rhs));
+    build_kkt(H, g, C, lb, ub, ws, idx, m, M, rhs);
     if (lin_solve(M, rhs, n)) return ORACLE_NOT_PD;
     double d[NV];
     for (int k = 0; k < NV; k++) d[k] = rhs[k] - f[k];
@@ -372,9 +375,12 @@ int oracle_qp_solve(const double* H, const double* g, const double* C, const dou
       if (viol > 1e-15 * gs && (bland ? (worst < 0 || idx[t] < idx[worst]) : viol > wv)) { wv = viol; worst = t; }
     }
     if (worst < 0) {
-      double xr[KMAX];
-      if (g_refine && lin_solve_ld(M0, rhs0, n, xr) == 0)
-        for (int k = 0; k < NV; k++) f[k] = xr[k];
+      if (g_refine) {  /* (lin_solve worked in place: the system of the accepted working set is built once more) */
+        double M0[KMAX * KMAX], rhs0[KMAX], xr[KMAX];
+        build_kkt(H, g, C, lb, ub, ws, idx, m, M0, rhs0);
+        if (lin_solve_ld(M0, rhs0, n, xr) == 0)
+          for (int k = 0; k < NV; k++) f[k] = xr[k];
+      }
       /* a checker must not certify an infeasible point: nearly parallel rows (mu -> 0) can defeat the
        * dependent-row logic above; report failure instead of a wrong ORACLE_OK */
       double fs = 1.0; /* scale of the solution: the KKT solves leave ~cond*eps*|f| on the pinned rows */
