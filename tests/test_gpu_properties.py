@@ -225,7 +225,7 @@ def test_dense_W_path(q, monkeypatch):
     assert np.max(np.abs(o["grf_body"] - ref2) / scale2) < 1e-6
 
 
-@pytest.mark.parametrize("n", [1000, 40000, 150000])  # G = 4, G = 2 single fill, G = 2 persistent waves
+@pytest.mark.parametrize("n", [1000, 40000, 150000])  # four lanes per robot with racing strategies; one lane per robot (one and three rounds of one-fill waves)
 def test_fused_tick_fk_and_torques(q, n):
     """joint_q in, joint_tau out (SURVEY 8f rows 1+2): device FK -> control -> clamp(J^T f)
     against the oracle's composition, and against the unfused path fed with the oracle's feet."""
