@@ -220,6 +220,46 @@ def test_iteration_cap_and_bad_inputs_agree_across_widths(q, cap):
     assert np.max(np.abs(r["grf_body"][ok] - ref["grf_body"][ok]) / scale) < 1e-8
 
 
+@pytest.mark.parametrize("form", ["uniform", "general", "dense"])
+def test_planner_boundaries_vs_oracle(q, form):
+    """Default settings at every batch size where the planner changes the kernel (racing strategies <= 4 096, four lanes
+    <= 16 384, two <= 32 768, one above; single robots; ragged last waves), cold and warm-started: oracle parity and the
+    launch the planner reports."""
+    import torch
+
+    from oracle import c_oracle as O
+    from quadruped_control_amd import workloads as W
+
+    P = q.cheetah_params(0.6)
+    sizes = [1, 3, 4, 5, 15, 16, 17, 63, 64, 65, 4095, 4096, 4097, 16383, 16384, 16385, 32767, 32768, 32769, 65535, 65537]
+    if form == "dense":
+        sizes = [1, 5, 17, 64, 65, 4096, 4097, 16384, 16385, 20001]
+    nmax = max(sizes)
+    prev, cur = W.config4(nmax, seed=0x5EED00E1)
+    mix = W.config3(nmax, seed=0x5EED00E2)
+    # mixed contact states for the cold batch, config 4's two ticks (all feet in stance) for the warm one
+    ref_cold, st, _ = O.control_batch(P, mix, threads=8)
+    ref_warm, st2, _ = O.control_batch(P, cur, threads=8)
+    assert (st == 0).all() and (st2 == 0).all()
+    ctl = q.BalanceController.from_params(P).set_tuning(**FORMS[form])
+    word = ctl.control_batch(q.to_device(prev), want_active_set=True)["active_set"]
+    seen = set()
+    for n in sizes:
+        info = ctl.query_launch(n)
+        seen.add((info["lanes_per_robot"], info["mode"], info["strategies"]))
+        if form != "dense":
+            assert info["lanes_per_robot"] == (4 if n <= 16384 else (2 if n <= 32768 else 1)), (n, info)
+            assert info["strategies"] == (4 if n <= 4096 else 1), (n, info)
+        cold = ctl.control_batch(q.to_device({k: v[:n] for k, v in mix.items()}), want_iterations=True)
+        warm = ctl.control_batch(q.to_device({k: v[:n] for k, v in cur.items()}), warm=word[:n].contiguous(), want_iterations=True)
+        torch.cuda.synchronize()
+        assert int((cold["status"] != 0).sum()) == 0 and int((warm["status"] != 0).sum()) == 0, n
+        assert _relerr(cold["grf_body"].cpu().numpy(), ref_cold[:n]) < RTOL, n
+        assert _relerr(warm["grf_body"].cpu().numpy(), ref_warm[:n]) < RTOL, n
+        assert float(warm["iterations"].float().mean()) <= float(cold["iterations"].float().mean()) or n < 64, n
+    assert len(seen) >= (4 if form != "dense" else 2), seen
+
+
 @pytest.mark.parametrize("steps", [0, 2, 3, 6])
 @pytest.mark.parametrize("form,G", [("uniform", 1), ("uniform", 2), ("uniform", 4), ("general", 1), ("general", 2), ("dense", 1)])
 def test_clamp_steps_vs_oracle(q, form, G, steps):
