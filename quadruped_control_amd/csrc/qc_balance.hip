@@ -1138,7 +1138,9 @@ static int plan_launch(qc_handle* h, long n, bool kin, bool warm, qc_launch_plan
     if (G == 4 && !QC_NO_STRIDED && h->chunk_override <= 0 && (mode == 2 || form != QC_FORM_UNIFORM)) {
       // (a 2-way race up to 8 192 robots is built and selectable - qc_set_tuning("race", 2) - but measured neutral on
       // average: its two fewer recalculations pay for the heavier body, tools/race_scan.py)
-      race = n <= 4 * simds ? 4 : 1;
+      // (cold batches: a warm-started one has little chain to shorten - 10-17 us either way, 0.2-0.6 us dearer with the race,
+      // tools/warm_race_scan.py)
+      race = (!warm && n <= 4 * simds) ? 4 : 1;
       if (h->race_override >= 0) race = (h->race_override == 4 && n <= 4 * simds) ? 4 : ((h->race_override >= 2 && n <= 8 * simds) ? 2 : 1);
       chunk = 16 / race;
     }

@@ -369,6 +369,9 @@ def test_racing_strategies_vs_oracle(q, form, n, strategies, start):
     if strategies == 2:
         assert race.query_launch(n)["strategies"] == 1  # the 2-way race is built but not the default (measured neutral)
         race.set_tuning(race=2)
+    elif start == "warm":
+        assert race.query_launch(n, warm=True)["strategies"] == 1  # warm-started batches do not race by default (measured neutral)
+        race.set_tuning(race=4)
     info = race.query_launch(n, warm=(start == "warm"))
     assert (info["form"], info["lanes_per_robot"], info["mode"], info["strategies"], info["chunk"]) == \
         (FORM_ID[form], 4, 2 if form == "uniform" else 1, strategies, 16 // strategies), info
