@@ -97,9 +97,9 @@ struct Lane {
       cand[3 * i + 2] = tag(C.sz[i] != 0 ? lz : QC_BIG, c0 + 2);
       if constexpr (RACE) {  // per-axis "this multiplier is negative" for the drop-all strategy (compares; the masks live in SGPRs)
         const double thr = -P.tol_d * gs;
-        neg[3 * i + 0] = C.sx[i] != 0 && lx < thr;
-        neg[3 * i + 1] = C.sy[i] != 0 && ly < thr;
-        neg[3 * i + 2] = C.sz[i] != 0 && lz < thr;
+        neg[3 * i + 0] = (C.sx[i] != 0) & (lx < thr);
+        neg[3 * i + 1] = (C.sy[i] != 0) & (ly < thr);
+        neg[3 * i + 2] = (C.sz[i] != 0) & (lz < thr);
       } else {
         neg[3 * i + 0] = neg[3 * i + 1] = neg[3 * i + 2] = false;
       }
@@ -175,10 +175,11 @@ struct Lane {
 #pragma unroll
         for (int k = 0; k < w / 2; k++) cand[k] = min_nn(cand[k], cand[k + (w + 1) / 2]);
       const double amin = group_min<G, S>(cand[0]);
-      blocked = !fresh && (amin < 1.0e299);
+      blocked = !fresh & (amin < 1.0e299);
       bcode = blocked ? tag_code(amin) : -1;
-      // f <- f^ + (1 - alpha)(f - f^): exactly f^ for a full step
-      const double beta = blocked ? 1.0 - max_nn(amin, 0.0) : 0.0;
+      // f <- f^ + (1 - alpha)(f - f^): exactly f^ for a full step.  No face blocks: amin = +BIG, clamped to alpha = 1
+      // (branch-free; a blocking ratio that the approximate reciprocal rounds up to 1 is clamped too)
+      const double beta = 1.0 - min_nn(max_nn(amin, 0.0), 1.0);
 #pragma unroll
       for (int k = 0; k < 3 * FPL; k++) f[k] = fresh ? fc[k] : __builtin_fma(beta, f[k] - fh[k], fh[k]);
     } else {
@@ -191,8 +192,8 @@ struct Lane {
     bool neg[3 * FPL];
     const bool opt = multipliers_ok(P, g, wcode, neg);
     if (!at_fh) wcode = -1;
-    const bool dall = RACE && drop_all && at_fh;  // this lane's strategy drops every negative multiplier at once
-    const bool take_clamp = fresh && changed;
+    const bool dall = RACE & drop_all & at_fh;  // this lane's strategy drops every negative multiplier at once
+    const bool take_clamp = fresh & changed;
 #pragma unroll
     for (int i = 0; i < FPL; i++) {
       int sx = C.sx[i], sy = C.sy[i], sz = C.sz[i];
@@ -207,9 +208,10 @@ struct Lane {
       C.sy[i] = live ? (take_clamp ? Cc.sy[i] : sy) : C.sy[i];
       C.sz[i] = live ? (take_clamp ? Cc.sz[i] : sz) : C.sz[i];
     }
-    const bool solved = pd && at_fh && opt;
+    // (bitwise on purpose: short-circuit forms become exec-mask branches on the serial chain)
+    const bool solved = pd & at_fh & opt;
     status = live ? (!pd ? (int)QC_NOT_PD : (solved ? (int)QC_SOLVED : status)) : status;  // otherwise it stays QC_MAX_ITER
-    return !pd || solved || iters >= P.max_iter;
+    return (!pd) | solved | (iters >= P.max_iter);
   }
 
   // take the robot staged in `slot` of the wave's input stock into this lane's group
@@ -586,13 +588,13 @@ QC_DEV void finish_on_four_lanes(const DevParams* __restrict__ Pg, const LaneG& 
         QC_CLK(7, 2);
         pin_uconst(uc);
         const bool done = L4.template iterate<Lane4::STEADY>(uc, eqp4, busy4);
-        busy4 = busy4 && !done;
+        busy4 = busy4 & !done;
       }
     } else if constexpr (STR4) {
       while (__builtin_popcountll(__builtin_amdgcn_ballot_w64(busy4) & 0xFFFFull) > stop) {
         QC_CLK(7, 2);
         const bool done = L4.template iterate<Lane4::STEADY>(*QC_PARAMS_HERE(Pg), eqp4, busy4);
-        busy4 = busy4 && !done;
+        busy4 = busy4 & !done;
       }
     } else {
       while (busy4) busy4 = !L4.template iterate<Lane4::STEADY>(*QC_PARAMS_HERE(Pg), eqp4);
@@ -619,10 +621,10 @@ QC_DEV void finish_on_four_lanes(const DevParams* __restrict__ Pg, const LaneG& 
     LR.drop_all = sid == 1;
     unsigned solved_mask = 0;  // strategies of this lane's robot that have reached the KKT point
     auto after = [&](bool done) {
-      const int mine = (busyR && done && LR.status == QC_SOLVED) ? (1 << sid) : 0;
+      const int mine = (busyR & done & (LR.status == QC_SOLVED)) ? (1 << sid) : 0;
       const int m = mine | __builtin_amdgcn_update_dpp(0, mine, 0x120 + 8, 0xF, 0xF, true);  // row_ror 8: the partner group
       solved_mask |= (unsigned)m;
-      busyR = busyR && !done && solved_mask == 0;
+      busyR = busyR & !done & (solved_mask == 0);
     };
     if constexpr (UNIFORM) {
       UConst uc = load_uconst(*QC_PARAMS_HERE(Pg));
@@ -723,16 +725,16 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
       // the robot is finished as soon as one strategy has solved it; the others stop with it
       auto after = [&](bool done) {
         if constexpr (RACE > 1) {
-          const int mine = (busy && done && L.status == QC_SOLVED) ? (1 << sid) : 0;
+          const int mine = (busy & done & (L.status == QC_SOLVED)) ? (1 << sid) : 0;
           int m = mine | __builtin_amdgcn_update_dpp(0, mine, 0x120 + ROB, 0xF, 0xF, true);  // row_ror by ROB lanes: the partner groups
           if constexpr (RACE == 4) {
             m |= __builtin_amdgcn_update_dpp(0, mine, 0x120 + 2 * ROB, 0xF, 0xF, true);
             m |= __builtin_amdgcn_update_dpp(0, mine, 0x120 + 3 * ROB, 0xF, 0xF, true);
           }
           solved_mask |= (unsigned)m;
-          busy = busy && !done && solved_mask == 0;
+          busy = busy & !done & (solved_mask == 0);
         } else {
-          busy = busy && !done;
+          busy = busy & !done;
         }
       };
       QC_CLK(0, 2);
