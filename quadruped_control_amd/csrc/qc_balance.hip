@@ -219,7 +219,12 @@ struct Lane {
   QC_DEV void load_from_stock(const double* __restrict__ sin, int slot, int member) {
     foot0 = member * FPL;
 #pragma unroll
-    for (int k = 0; k < 6; k++) Wr.b[k] = sin[(IN_B + k) * SP + slot];
+    for (int k = 0; k < 6; k++) {
+      Wr.b[k] = Eqp::kNegB ? -sin[(IN_B + k) * SP + slot] : sin[(IN_B + k) * SP + slot];
+      // (opaque: otherwise the compiler keeps +b and re-materialises the negation - an MFMA addend takes no source
+      // modifier - inside every recalculation)
+      if constexpr (Eqp::kNegB) asm volatile("" : "+v"(Wr.b[k]));
+    }
 #pragma unroll
     for (int i = 0; i < FPL; i++)
 #pragma unroll
@@ -521,7 +526,10 @@ QC_DEV void repack_write(const LaneX& L, double* __restrict__ rec, int slot, int
 template <class Lane4X, class Eqp4X>
 QC_DEV int repack_read(const DevParams* __restrict__ Pg, Lane4X& L4, Eqp4X& eqp4, const double* __restrict__ rec, int j4) {
 #pragma unroll
-  for (int k = 0; k < 6; k++) L4.Wr.b[k] = rec[k];
+  for (int k = 0; k < 6; k++) {
+    L4.Wr.b[k] = rec[k];  // (already -b: both sides are 6x6 forms)
+    asm volatile("" : "+v"(L4.Wr.b[k]));
+  }
 #pragma unroll
   for (int k = 0; k < 3; k++) {
     L4.Wr.r[0][k] = rec[8 + 3 * j4 + k];

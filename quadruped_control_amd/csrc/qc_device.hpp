@@ -827,7 +827,7 @@ QC_DEV bool eqp_diagw(const PT& P, const FootW (&lane_w)[4 / G], const Wrench<4 
       else if (r == c) M[MI(r, c)] = group_sum_add<G, S>(M[MI(r, c)], P.Vd[r]);  // S^-1 is diagonal here
       else M[MI(r, c)] = group_sum<G, S>(M[MI(r, c)]);
     }
-    rhs[r] = group_sum_add<G, S>(rhs[r], -Wr.b[r]);
+    rhs[r] = group_sum_add<G, S>(rhs[r], Wr.b[r]);  // (the 6x6 forms keep -b in Wr.b: kNegB, Lane::load_from_stock)
   }
   QC_CLK_PIN(M); QC_CLK_PIN(rhs);
   QC_CLK(3, 4);
@@ -914,6 +914,7 @@ struct EqpDiagW {
   static constexpr bool kStrided = STRIDED;  // lane layout of the group, see group_sum
   static constexpr bool kUniform = UNIFORM;
   static constexpr bool kRepackTail = GROUP <= 2;  // one-fill waves finish their stragglers 4 lanes per robot
+  static constexpr bool kNegB = true;  // the lane keeps -b (what the right-hand side adds), not b: no negation per recalculation
   FootW lane_w[4 / GROUP];  // general form with lane groups: the weights of this lane's feet (dead otherwise)
   QC_DEV explicit EqpDiagW(double*) {}
   // called when the lane takes a robot; `foot0` = first foot of the lane
@@ -947,6 +948,7 @@ struct EqpDense {
   static constexpr int G = 1;
   static constexpr bool kStrided = false;
   static constexpr bool kRepackTail = false;
+  static constexpr bool kNegB = false;
   double* Qs;    // LDS base of this lane: element k at Qs[k * 64]
   double c[12];  // c = -2 A^T S b (BC.cpp:153)
 
@@ -1116,6 +1118,7 @@ struct EqpDense4 {
   static constexpr bool kStrided = true;
   static constexpr bool kUniform = false;
   static constexpr bool kRepackTail = false;
+  static constexpr bool kNegB = false;
   static constexpr int XS = 17;           // tile stride in doubles (16 robots + 1)
   static constexpr int X_DOUBLES = 156 * XS;
   double* X;        // this robot's column of the wave's exchange tile
