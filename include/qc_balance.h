@@ -224,8 +224,7 @@ int qc_query_launch(qc_handle* h, size_t n, int kin, int warm, qc_launch_info* o
  * library reads NO environment variables).  Keys: "group" (lanes per robot: 0 = heuristic, 1, 2, 4), "one_fill"
  * (-1 heuristic, 0 persistent waves, 1 one-fill workgroups), "chunk" (robots per wave, 0 = heuristic),
  * "wave_slots" (resident workgroups assumed, 0 = occupancy query), "refill_t", "rounds_cold", "rounds_warm",
- * "race" (-1 heuristic; 0 or 1: one strategy per robot, also in the straggler tail of the wider kernels; 2, 4: at most
- * that many racing in the 4-lane one-fill kernels),
+ * "race" (-1 heuristic; 0 or 1: one strategy per robot; 2, 4: at most that many racing in the 4-lane one-fill kernels),
  * "force_general" / "force_dense" (run the more general formulation on weights that would allow the
  * specialised one; same minimiser), "clamp_steps" (clamp steps a cold-started robot takes before its first ratio test in
  * the one-fill kernels; 0 = the kernel's rule: five on one or two lanes per robot, one on four),
