@@ -582,6 +582,51 @@ void oracle_leg_ik(const oracle_kinematics* k, int leg, const double* foothold, 
   q[1] = -atan2(x, sqrt(sqrt_component)) - atan2(l3 * sin(q[2]), l2 + l3 * cos(q[2]));
 }
 
+/* arma::pinv of a 3x3 (kinematics.cpp:196): Moore-Penrose inverse from the singular value decomposition with
+ * Armadillo's default tolerance max(m, n) * sigma_max * epsilon.  The SVD here is the one-sided Jacobi method
+ * (Hestenes): columns of A = J V are rotated pairwise until orthogonal, then sigma_i = |a_i|, u_i = a_i / sigma_i,
+ * which keeps tiny singular values accurate (nothing is squared).  pinv = sum over sigma_i > tol of v_i u_i^T / sigma_i.
+ * Returns 0 if the sweeps do not converge (never observed; the caller then falls through to J^T as the reference does). */
+int oracle_pinv3(const double* J, double* Jp) {
+  double A[3][3], V[3][3];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) { A[i][j] = J[3 * i + j]; V[i][j] = (i == j) ? 1.0 : 0.0; }
+  int converged = 0;
+  for (int sweep = 0; sweep < 60 && !converged; sweep++) {
+    converged = 1;
+    for (int p = 0; p < 2; p++)
+      for (int q = p + 1; q < 3; q++) {
+        double alpha = 0.0, beta = 0.0, gamma = 0.0;
+        for (int i = 0; i < 3; i++) { alpha += A[i][p] * A[i][p]; beta += A[i][q] * A[i][q]; gamma += A[i][p] * A[i][q]; }
+        if (gamma == 0.0 || fabs(gamma) <= 2.220446049250313e-16 * sqrt(alpha * beta)) continue; /* orthogonal to working precision */
+        converged = 0;
+        const double zeta = (beta - alpha) / (2.0 * gamma);
+        const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+        for (int i = 0; i < 3; i++) {
+          const double ap = A[i][p], aq = A[i][q];
+          A[i][p] = c * ap - s * aq; A[i][q] = s * ap + c * aq;
+          const double vp = V[i][p], vq = V[i][q];
+          V[i][p] = c * vp - s * vq; V[i][q] = s * vp + c * vq;
+        }
+      }
+  }
+  if (!converged) return 0;
+  double sig[3], smax = 0.0;
+  for (int j = 0; j < 3; j++) {
+    sig[j] = sqrt(A[0][j] * A[0][j] + A[1][j] * A[1][j] + A[2][j] * A[2][j]);
+    if (sig[j] > smax) smax = sig[j];
+  }
+  const double tol = 3.0 * smax * 2.220446049250313e-16;
+  for (int i = 0; i < 9; i++) Jp[i] = 0.0;
+  for (int j = 0; j < 3; j++) {
+    if (!(sig[j] > tol)) continue;
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) Jp[3 * r + c] += V[r][j] * A[c][j] / (sig[j] * sig[j]); /* v_j u_j^T / sigma_j, u_j = a_j / sigma_j */
+  }
+  return 1;
+}
+
 void oracle_swing_torque(const oracle_kinematics* k, int leg, const double* Rwb, const double* x, const double* pos,
                          const double* vel, const double* q, const double* qdot, double* tau) {
   double pb[3], vb[3], qr[3], J[9], Jinv[9], qd[3];
@@ -592,11 +637,13 @@ void oracle_swing_torque(const oracle_kinematics* k, int leg, const double* Rwb,
   oracle_leg_ik(k, leg, pb, qr);          /* :495 */
   oracle_leg_jacobian(k, leg, qr, J);     /* legJacobianInverse, kinematics.cpp:190-204 */
   {
-    /* Gauss-Jordan with partial pivoting (what arma::inv / LAPACK getrf+getri amounts to for a 3x3).
-     * A numerically singular J (leg fully stretched: the reference point is out of reach and IK clamps
-     * d to 1) gives a LAPACK-dependent garbage inverse in the reference; the restatement - and the device
-     * code - take the reference's last-resort branch J^T (:198) when |det| <= 1e-9 (|l1|+|l2|+|l3|)^3
-     * (the pinv branch of :196 is not reproduced). */
+    /* legJacobianInverse, kinematics.cpp:190-204: arma::inv, if that fails arma::pinv, if that fails J^T.
+     * inv: Gauss-Jordan with partial pivoting (what LAPACK getrf+getri amounts to for a 3x3).  A singular J - leg
+     * fully stretched: the reference point is out of reach and IK clamps d to 1, so q3 = 0 and the last two
+     * columns are parallel (rank 2; rank 1 when y^2 + z^2 < l1^2 is clamped as well) - takes the pinv branch
+     * (:196).  The switch: |det| <= 1e-9 (|l1|+|l2|+|l3|)^3 or an exact zero pivot (the reference's own switch is
+     * Armadillo's "|det| < epsilon, then LAPACK info != 0"; between the two thresholds arma::inv returns a
+     * 1/sigma_3-sized inverse whose torque the clamp of commander_node.cpp:526 saturates - INTEGRATION.md). */
     double M[3][6];
     const double det = J[0] * (J[4] * J[8] - J[5] * J[7]) + J[1] * (J[5] * J[6] - J[3] * J[8]) + J[2] * (J[3] * J[7] - J[4] * J[6]);
     const double lsum = fabs(k->links[3 * leg]) + fabs(k->links[3 * leg + 1]) + fabs(k->links[3 * leg + 2]);
@@ -616,8 +663,13 @@ void oracle_swing_torque(const oracle_kinematics* k, int leg, const double* Rwb,
         for (int j = 0; j < 6; j++) M[r][j] -= m * M[c][j];
       }
     }
-    for (int i = 0; i < 3; i++)
-      for (int j = 0; j < 3; j++) Jinv[3 * i + j] = singular ? J[3 * j + i] : M[i][3 + j];
+    if (!singular) {
+      for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) Jinv[3 * i + j] = M[i][3 + j];
+    } else if (!oracle_pinv3(J, Jinv)) {
+      for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) Jinv[3 * i + j] = J[3 * j + i]; /* :198 */
+    }
   }
   for (int r = 0; r < 3; r++) qd[r] = Jinv[3 * r] * vb[0] + Jinv[3 * r + 1] * vb[1] + Jinv[3 * r + 2] * vb[2]; /* :496-497 */
   for (int c = 0; c < 3; c++) { /* joint_controller.cpp:28-36 */

@@ -98,6 +98,9 @@ void oracle_tick_batch(const oracle_params* P, const oracle_kinematics* K, long 
                        int* status, int threads);
 /* legInverseKinematics(leg, foothold), kinematics.cpp:117-160 */
 void oracle_leg_ik(const oracle_kinematics* k, int leg, const double* p3, double* q3);
+/* arma::pinv of a 3x3, the fallback of legJacobianInverse (kinematics.cpp:196): SVD (one-sided Jacobi) with
+ * Armadillo's default tolerance 3 * sigma_max * epsilon; Jp9 row-major.  Returns 0 if the SVD did not converge. */
+int oracle_pinv3(const double* J9, double* Jp9);
 /* Swing-leg torque of one leg as commander_node.cpp:482-504 + joint_controller.cpp:21-39 compute it (unclamped):
  * pos/vel = world-frame reference foot state, q/qdot = measured joint state of the leg. */
 void oracle_swing_torque(const oracle_kinematics* k, int leg, const double* Rwb, const double* x, const double* pos,

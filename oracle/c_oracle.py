@@ -157,6 +157,23 @@ def leg_ik(leg, p, kin=None):
     return q
 
 
+def pinv3(J):
+    """oracle_pinv3: the pseudo-inverse legJacobianInverse falls back to (kinematics.cpp:196)."""
+    J = np.ascontiguousarray(J, np.float64).reshape(9); out = np.zeros(9)
+    lib().oracle_pinv3.restype = C.c_int
+    ok = lib().oracle_pinv3(_dp(J), _dp(out))
+    return out.reshape(3, 3), bool(ok)
+
+
+def swing_torque(leg, Rwb, x, pos, vel, q, qdot, kin=None):
+    """oracle_swing_torque of one leg (unclamped)."""
+    kin = kin or default_kinematics()
+    a = [np.ascontiguousarray(v, np.float64).reshape(-1) for v in (Rwb, x, pos, vel, q, qdot)]
+    tau = np.zeros(3)
+    lib().oracle_swing_torque(C.byref(kin), C.c_int(leg), *[_dp(v) for v in a], _dp(tau))
+    return tau
+
+
 def tick_swing_batch(P, batch, kin=None, threads=1, max_iter=200):
     """tick_batch + swing-leg torques; batch also holds joint_qdot, swing_pos, swing_vel [n,12]."""
     kin = kin or default_kinematics()

@@ -249,6 +249,44 @@ struct Lane {
     have_f = false;
   }
 
+  // take a freshly assembled robot straight from registers (one lane per robot, no stock in between)
+  QC_DEV void load_direct(const Wrench<FPL>& W, uint32_t st, uint32_t wv, long robot, int member) {
+    static_assert(G == 1, "one lane assembles and solves the whole robot");
+    foot0 = member * FPL;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      Wr.b[k] = Eqp::kNegB ? -W.b[k] : W.b[k];
+      if constexpr (Eqp::kNegB) asm volatile("" : "+v"(Wr.b[k]));
+    }
+#pragma unroll
+    for (int i = 0; i < FPL; i++)
+#pragma unroll
+      for (int k = 0; k < 3; k++) Wr.r[i][k] = W.r[i][k];
+    stance = st;
+    idx = robot;
+    const bool use_warm = (wv & 0x80000000u) != 0;
+#pragma unroll
+    for (int i = 0; i < FPL; i++) {
+      const uint32_t fb = wv >> (6 * (foot0 + i));
+      const bool on = use_warm && ((stance >> (foot0 + i)) & 1u);
+      C.sx[i] = on ? dec2(fb) : 0;
+      C.sy[i] = on ? dec2(fb >> 2) : 0;
+      C.sz[i] = on ? dec2(fb >> 4) : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < 3 * FPL; k++) f[k] = 0.0;
+    status = QC_MAX_ITER;
+    iters = 0;
+    have_f = false;
+  }
+  // the working-set word of this lane's feet (bit 31 = valid is added by the caller)
+  QC_DEV uint32_t word_bits() const {
+    uint32_t word = 0;
+#pragma unroll
+    for (int i = 0; i < FPL; i++) word |= encode_foot(C.sx[i], C.sy[i], C.sz[i]) << (6 * (foot0 + i));
+    return word;
+  }
+
   // park the finished robot's result in `slot` of the wave's output stock
   template <int SP>
   QC_DEV void push_result(double* __restrict__ sout, int slot) const {
@@ -323,14 +361,11 @@ QC_DEV void swing_plan(CParams& P, const BatchIn& in, long robot, int foot0, uin
   }
 }
 
-// FPL = 4: one lane assembles a whole robot (dense restock of a big batch);
-// FPL = 4/G: the G lanes of a group share a robot, each doing its own feet
-// (small fills, where latency matters more than lane efficiency).
-template <bool KIN, int FPL, bool STR, int SP>
-QC_DEV void assemble_to_stock(CParams& P, const BatchIn& in, const uint32_t* __restrict__ warm, long robot, int slot, int member,
-                              double* __restrict__ sin) {
+// the assembly of one robot (or of this lane's feet of it): wrench target and lever arms, contact state, optional
+// gait clock and swing planning.  Returns the stance word (bits 0-3 LegState, bit 8 = non-finite input).
+template <bool KIN, int FPL, bool STR>
+QC_DEV uint32_t assemble_robot(CParams& P, const BatchIn& in, long robot, int member, Wrench<FPL>& W) {
   constexpr int GG = 4 / FPL;
-  Wrench<FPL> W;
   const int foot0 = member * FPL;
   const double fin = build_wrench<FPL, KIN>(P, in, robot, foot0, W);
   uint32_t stance = 0xFu;  // make_stance_gait(), gait.cpp:24-34
@@ -364,31 +399,46 @@ QC_DEV void assemble_to_stock(CParams& P, const BatchIn& in, const uint32_t* __r
     }
   }
   if (KIN && in.swing_state) swing_plan<FPL, STR>(P, in, robot, foot0, stance);
-  const uint32_t wv = warm ? warm[robot] : 0u;
   // non-finite inputs poison b, r or R: report QC_NOT_PD instead of iterating on NaNs
   const bool bad = group_or<GG, STR>(!(fin == 0.0) ? 1 : 0) != 0;
-  if (bad) stance |= 0x100u;
+  if (bad) {
+    stance |= 0x100u;
+#pragma unroll
+    for (int k = 0; k < 6; k++) W.b[k] = 0.0;
+#pragma unroll
+    for (int i = 0; i < FPL; i++) W.r[i][0] = W.r[i][1] = W.r[i][2] = 0.0;
+  }
+  return stance;
+}
+
+// FPL = 4: one lane assembles a whole robot (dense restock of a big batch);
+// FPL = 4/G: the G lanes of a group share a robot, each doing its own feet
+// (small fills, where latency matters more than lane efficiency).
+template <bool KIN, int FPL, bool STR, int SP>
+QC_DEV void assemble_to_stock(CParams& P, const BatchIn& in, const uint32_t* __restrict__ warm, long robot, int slot, int member,
+                              double* __restrict__ sin) {
+  Wrench<FPL> W;
+  const int foot0 = member * FPL;
+  const uint32_t stance = assemble_robot<KIN, FPL, STR>(P, in, robot, member, W);
+  const uint32_t wv = warm ? warm[robot] : 0u;
 #pragma unroll
   for (int i = 0; i < FPL; i++)
 #pragma unroll
-    for (int k = 0; k < 3; k++) sin[(IN_R + 3 * (foot0 + i) + k) * SP + slot] = bad ? 0.0 : W.r[i][k];
+    for (int k = 0; k < 3; k++) sin[(IN_R + 3 * (foot0 + i) + k) * SP + slot] = W.r[i][k];
   if (member == 0) {
 #pragma unroll
-    for (int k = 0; k < 6; k++) sin[(IN_B + k) * SP + slot] = bad ? 0.0 : W.b[k];
+    for (int k = 0; k < 6; k++) sin[(IN_B + k) * SP + slot] = W.b[k];
     sin[IN_FLAGS * SP + slot] = __longlong_as_double((long long)(((unsigned long long)wv << 32) | stance));
     sin[IN_IDX * SP + slot] = __longlong_as_double(robot);
   }
 }
 
-// output transform, BC.cpp:218-232: fb = -Rwb^T fw for stance legs; optional torque map
-template <bool KIN, int FPL, int SP>
-QC_DEV void store_from_stock(CParams& P, const BatchIn& in, const BatchOut& out, const double* __restrict__ sout, int slot, int member) {
+// output transform, BC.cpp:218-232: fb = -Rwb^T fw for stance legs; optional torque map.  `fw` = world-frame forces of
+// the FPL feet from foot0 on; `member` 0 also writes the per-robot words.
+template <bool KIN, int FPL>
+QC_DEV void store_result(CParams& P, const BatchIn& in, const BatchOut& out, long idx, uint32_t stance, int status, int iters, uint32_t word,
+                         const double (&fw)[3 * FPL], int member) {
   const int foot0 = member * FPL;
-  const long idx = __double_as_longlong(sout[OUT_IDX * SP + slot]);
-  const unsigned long long sw = (unsigned long long)__double_as_longlong(sout[OUT_STAT * SP + slot]);
-  const unsigned long long ww = (unsigned long long)__double_as_longlong(sout[OUT_WORD * SP + slot]);
-  const int status = (int)(uint32_t)sw, iters = (int)(uint32_t)(sw >> 32);
-  const uint32_t word = (uint32_t)ww, stance = (uint32_t)(ww >> 32);
   const double* Rp = in.Rwb + 9 * idx;
   double R[9];
 #pragma unroll
@@ -400,7 +450,7 @@ QC_DEV void store_from_stock(CParams& P, const BatchIn& in, const BatchOut& out,
     const bool st = ((stance >> (foot0 + i)) & 1u) && st_out == QC_SOLVED;
     double f[3], fb[3];
 #pragma unroll
-    for (int k = 0; k < 3; k++) f[k] = sout[(OUT_F + 3 * (foot0 + i) + k) * SP + slot];
+    for (int k = 0; k < 3; k++) f[k] = fw[3 * i + k];
 #pragma unroll
     for (int r = 0; r < 3; r++) {
       const double v = -(R[r] * f[0] + R[3 + r] * f[1] + R[6 + r] * f[2]);
@@ -462,6 +512,18 @@ QC_DEV void store_from_stock(CParams& P, const BatchIn& in, const BatchOut& out,
     if (out.active_set) out.active_set[idx] = word;
     if (out.iterations) out.iterations[idx] = iters;
   }
+}
+
+template <bool KIN, int FPL, int SP>
+QC_DEV void store_from_stock(CParams& P, const BatchIn& in, const BatchOut& out, const double* __restrict__ sout, int slot, int member) {
+  const int foot0 = member * FPL;
+  const long idx = __double_as_longlong(sout[OUT_IDX * SP + slot]);
+  const unsigned long long sw = (unsigned long long)__double_as_longlong(sout[OUT_STAT * SP + slot]);
+  const unsigned long long ww = (unsigned long long)__double_as_longlong(sout[OUT_WORD * SP + slot]);
+  double fw[3 * FPL];
+#pragma unroll
+  for (int k = 0; k < 3 * FPL; k++) fw[k] = sout[(OUT_F + 3 * foot0 + k) * SP + slot];
+  store_result<KIN, FPL>(P, in, out, idx, (uint32_t)(ww >> 32), (int)(uint32_t)sw, (int)(uint32_t)(sw >> 32), (uint32_t)ww, fw, member);
 }
 
 // dense assembly of the next (up to 64) robots of the chunk into the input stock; returns how many
@@ -913,6 +975,7 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
   QC_CLK_END(8);
 }
 
+
 }  // namespace qc
 
 // =============================================================== host / C ABI
@@ -1077,6 +1140,7 @@ static qc_kernel_fn kernel_for(int form, int G, int mode, bool kin, int minw = 2
   return mode ? kernel_of<EqpDiagW<true, 1>, 2, 1>(kin) : kernel_of<EqpDiagW<true, 1>, 2, 0>(kin);
 }
 static size_t lds_for(int form, int G, int mode) {
+
   const size_t stock = (size_t)qc::stock_doubles(qc::stock_slots(G, mode)) * sizeof(double);
   if (form == QC_FORM_DENSE) return stock + (G == 4 ? (size_t)qc::EqpDense4::X_DOUBLES : (size_t)78 * 64) * sizeof(double);
   return stock;
@@ -1245,6 +1309,11 @@ int qc_create(const qc_params* p, int device, qc_handle** out) {
   if (device < 0 || device >= ndev) return fail(QC_ERR_INVALID, "qc_create: device ordinal out of range");
   if (!(p->mu > 0.0) || !(p->mass > 0.0)) return fail(QC_ERR_INVALID, "qc_create: mu and mass must be > 0");
   if (!(p->fzmin >= 0.0) || !(p->fzmax >= p->fzmin)) return fail(QC_ERR_INVALID, "qc_create: need 0 <= fzmin <= fzmax");
+  // The cone rows of the reference are two-sided with +-1e6 on the far side (BC.cpp:296-301: -1e6 <= fx - mu fz <= 0, ...).
+  // Inside the cone |fx -+ mu fz| <= 2 mu fz <= 2 mu fzmax, so those sides cannot bind - and this solver does not carry
+  // them - as long as 2 mu fzmax < 1e6.  Parameters beyond that would make the reference's QP a different one: refused.
+  if (!(2.0 * p->mu * p->fzmax < 1.0e6))
+    return fail(QC_ERR_INVALID, "qc_create: need 2 * mu * fzmax < 1e6 (the +-1e6 sides of the reference's cone rows, balance_controller.cpp:296-301, are not carried)");
   for (int i = 0; i < 6; i++)
     for (int j = 0; j < i; j++)
       if (std::fabs(p->S[6 * i + j] - p->S[6 * j + i]) > 1e-12 * (std::fabs(p->S[6 * i + i]) + std::fabs(p->S[6 * j + j])))

@@ -419,6 +419,72 @@ QC_DEV double normalize_angle_PI(double rad) {
   if (rad < 0.0) rad += two_pi;
   return rad - pi;
 }
+// x = pinv(J) v for a rank-deficient 3x3 J - arma::pinv, the second branch of legJacobianInverse (kinematics.cpp:196).
+// No SVD on the device: two steps of Gaussian elimination with COMPLETE pivoting give a full-rank factorisation
+// J = C F (C = the pivot columns of the running remainder, 3 x r; F = its pivot rows scaled by the pivots, r x 3), and
+// the Moore-Penrose inverse of a full-rank product is F^T (F F^T)^-1 (C^T C)^-1 C^T.  r = 2 for the stretched leg (the
+// knee column is parallel to the hip-pitch column), r = 1 when the lateral clamp of kinematics.cpp:137-140 acts as well;
+// a second pivot below 1e-9 of the first counts as zero (it is ~1e-17 there, against ~0.1 at rank 2).  Agrees with the
+// SVD-based pinv of the oracle / numpy to 3e-14 relative on out-of-reach targets.  Rare, divergent path.
+QC_DEV void pinv3_apply(const double (&J)[9], const double (&v)[3], double (&x)[3]) {
+  double A[9], c[2][3], f[2][3];
+#pragma unroll
+  for (int k = 0; k < 9; k++) A[k] = J[k];
+  int rank = 0;
+  double piv1 = 0.0;
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    double best = -1.0;
+    int bi = 0, bj = 0;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        const double a = fabs(A[3 * i + j]);
+        const bool t = a > best;
+        best = t ? a : best; bi = t ? i : bi; bj = t ? j : bj;
+      }
+    if (k == 0) piv1 = best;
+    const bool take = k == 0 ? best > 0.0 : (rank == 1 && best > 1.0e-9 * piv1);
+    if (take) {
+      double col[3], row[3];
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        col[i] = bj == 0 ? A[3 * i] : (bj == 1 ? A[3 * i + 1] : A[3 * i + 2]);
+        row[i] = bi == 0 ? A[i] : (bi == 1 ? A[3 + i] : A[6 + i]);
+      }
+      const double ip = 1.0 / (bi == 0 ? col[0] : (bi == 1 ? col[1] : col[2]));
+#pragma unroll
+      for (int i = 0; i < 3; i++) { row[i] *= ip; c[k][i] = col[i]; f[k][i] = row[i]; }
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) A[3 * i + j] -= col[i] * row[j];
+      rank = k + 1;
+    }
+  }
+  x[0] = x[1] = x[2] = 0.0;
+  if (rank == 1) {
+    const double cv = c[0][0] * v[0] + c[0][1] * v[1] + c[0][2] * v[2];
+    const double cc = c[0][0] * c[0][0] + c[0][1] * c[0][1] + c[0][2] * c[0][2];
+    const double ff = f[0][0] * f[0][0] + f[0][1] * f[0][1] + f[0][2] * f[0][2];
+    const double s = cv / (cc * ff);
+#pragma unroll
+    for (int i = 0; i < 3; i++) x[i] = f[0][i] * s;
+  } else if (rank == 2) {
+    auto dot = [](const double (&a)[3], const double (&b)[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
+    const double g00 = dot(c[0], c[0]), g01 = dot(c[0], c[1]), g11 = dot(c[1], c[1]);  // C^T C
+    const double a0 = dot(c[0], v), a1 = dot(c[1], v);
+    const double ig = 1.0 / (g00 * g11 - g01 * g01);
+    const double b0 = ig * (g11 * a0 - g01 * a1), b1 = ig * (g00 * a1 - g01 * a0);
+    const double h00 = dot(f[0], f[0]), h01 = dot(f[0], f[1]), h11 = dot(f[1], f[1]);  // F F^T
+    const double ih = 1.0 / (h00 * h11 - h01 * h01);
+    const double d0 = ih * (h11 * b0 - h01 * b1), d1 = ih * (h00 * b1 - h01 * b0);
+#pragma unroll
+    for (int i = 0; i < 3; i++) x[i] = f[0][i] * d0 + f[1][i] * d1;
+  }
+}
+
 // Swing-leg torque of one leg, commander_node.cpp:482-504 + joint_controller.cpp:21-39.
 // pb, vb: desired foot position / velocity in the frame the reference hands to IK.
 QC_DEV void leg_swing_torque(CParams& P, int leg, const double (&pb)[3], const double (&vb)[3], const double* __restrict__ q,
@@ -436,16 +502,17 @@ QC_DEV void leg_swing_torque(CParams& P, int leg, const double (&pb)[3], const d
   qr[0] = right ? atan2(z, y) + atan2(rt, -l1) : -(atan2(z, -y) + atan2(rt, -l1));
   qr[2] = atan2(-sqrt(1.0 - d * d), d);
   qr[1] = -atan2(x, rt) - atan2(l3 * sin(qr[2]), l2 + l3 * cos(qr[2]));
-  // legJacobianInverse(q_ref) * vb, kinematics.cpp:190-204 (closed-form inverse; J^T if singular)
+  // legJacobianInverse(q_ref) * vb, kinematics.cpp:190-204 (arma::inv as the closed-form inverse; arma::pinv if singular)
   const LegTrig t = leg_trig(qr);
   const double L1 = P.links[3 * leg], L2 = P.links[3 * leg + 1], L3 = P.links[3 * leg + 2];
   const double a = L2 * t.c2 + L3 * t.c23, b = L2 * t.s2 + L3 * t.s23;
   const double J[9] = {0.0, a, L3 * t.c23, -L1 * t.s1 - a * t.c1, b * t.s1, L3 * t.s1 * t.s23, L1 * t.c1 - a * t.s1, -b * t.c1, -L3 * t.s23 * t.c1};
   const double c00 = J[4] * J[8] - J[5] * J[7], c01 = J[5] * J[6] - J[3] * J[8], c02 = J[3] * J[7] - J[4] * J[6];
   const double det = J[0] * c00 + J[1] * c01 + J[2] * c02;
-  // A (numerically) singular J - leg fully stretched because the reference point is out of reach, where IK
-  // clamps d to 1 - makes arma::inv's answer in the reference a LAPACK-dependent garbage value; here, as in
-  // the oracle, |det| <= 1e-9 (|l1|+|l2|+|l3|)^3 takes the reference's last-resort branch J^T (kinematics.cpp:198).
+  // A singular J - leg fully stretched because the reference point is out of reach, where IK clamps d to 1 and q3 = 0 -
+  // makes arma::inv fail in the reference and arma::pinv answer (kinematics.cpp:194-196).  The switch (the same in the
+  // checker under oracle/): |det| <= 1e-9 (|l1|+|l2|+|l3|)^3 (Armadillo's own: |det| < epsilon, then an exact zero LAPACK pivot - between the
+  // two the reference multiplies by a 1/sigma_3-sized inverse and the torque clamp saturates).
   const double lsum = fabs(L1) + fabs(L2) + fabs(L3);
   double qd[3];
   if (fabs(det) > 1.0e-9 * lsum * lsum * lsum) {
@@ -455,8 +522,7 @@ QC_DEV void leg_swing_torque(CParams& P, int leg, const double (&pb)[3], const d
     qd[1] = id * (c01 * vb[0] + (J[0] * J[8] - J[2] * J[6]) * vb[1] + (J[2] * J[3] - J[0] * J[5]) * vb[2]);
     qd[2] = id * (c02 * vb[0] + (J[1] * J[6] - J[0] * J[7]) * vb[1] + (J[0] * J[4] - J[1] * J[3]) * vb[2]);
   } else {
-#pragma unroll
-    for (int c = 0; c < 3; c++) qd[c] = J[c] * vb[0] + J[3 + c] * vb[1] + J[6 + c] * vb[2];
+    pinv3_apply(J, vb, qd);
   }
   // JointController::control, joint_controller.cpp:28-36
 #pragma unroll

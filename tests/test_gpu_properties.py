@@ -168,6 +168,19 @@ def test_edge_cases(q):
     bad = dict(P); bad["fzmin"] = 200.0
     with pytest.raises(RuntimeError, match="fzmin"):
         q.BalanceController.from_params(bad)
+    # the +-1e6 sides of the reference's cone rows (balance_controller.cpp:296-301) are not carried: parameter sets for
+    # which they could bind (2 mu fzmax >= 1e6) are refused, and just below the limit the oracle - which keeps the
+    # literal two-sided rows - still agrees
+    for mu, fzmax in ((0.6, 1.0e6), (2.0, 2.5e5), (50.0, 1.0e4)):
+        bad = dict(P); bad["mu"] = mu; bad["fzmax"] = fzmax
+        with pytest.raises(RuntimeError, match="1e6"):
+            q.BalanceController.from_params(bad)
+    edge = dict(P); edge["mu"] = 2.0; edge["fzmax"] = 2.4e5
+    b4 = W.config3(2048)
+    o4 = q.BalanceController.from_params(edge).control_batch_host(b4)
+    ref4, st4, _ = O.control_batch(edge, b4, threads=8)
+    assert (o4["status"] == 0).all() and (st4 == 0).all()
+    assert np.max(np.abs(o4["grf_body"] - ref4) / np.maximum(1.0, np.abs(ref4).max(axis=1, keepdims=True))) < 1e-6
 
 
 def test_general_S_and_per_axis_W(q):
@@ -378,6 +391,53 @@ def test_swing_leg_torques(q, n):
     bad = {k: v for k, v in b.items() if k != "swing_vel"}
     with pytest.raises(RuntimeError, match="go together"):
         ctl.control_batch_host(bad, want_torques=True)
+
+
+@pytest.mark.parametrize("n", [900, 70000])  # 4 lanes per robot (one foot per lane) and one lane per robot
+def test_swing_reference_out_of_reach_takes_pinv(q, n):
+    """legJacobianInverse's second branch (kinematics.cpp:194-196): a swing reference the leg cannot reach makes
+    legInverseKinematics clamp d to 1 (:131-134) - knee straight, J of rank 2, or rank 1 when the lateral clamp
+    (:137-140) acts too - and the reference's joint-velocity target is arma::pinv(J) v.  Device (complete-pivoting
+    full-rank factorisation) against the oracle (Jacobi SVD, Armadillo's tolerance); unclamped torques so that the
+    comparison sees the values, not the saturation."""
+    from oracle import c_oracle as O
+    from quadruped_control_amd import workloads as W
+
+    P = q.cheetah_params(0.6)
+    b = W.with_swing_references(W.with_joint_angles(W.config3(n)))
+    rng = np.random.default_rng(77)
+    hip = np.array([[-0.196, 0.05, 0.0], [0.196, 0.05, 0.0], [-0.196, -0.05, 0.0], [0.196, -0.05, 0.0]])
+    direction = rng.normal(size=(n, 4, 3))
+    direction[::5, :, 1:] *= 0.05                       # nearly along x: the lateral clamp as well -> rank 1
+    direction /= np.linalg.norm(direction, axis=-1, keepdims=True)
+    far = rng.random((n, 4)) < 0.5                      # half of the legs get an unreachable target
+    pb = hip[None] + direction * rng.uniform(0.55, 1.5, (n, 4, 1))   # reach: 0.077 + 0.211 + 0.230
+    R = b["Rwb"].reshape(n, 3, 3)
+    pos_far = np.einsum("nij,nkj->nki", R, pb + b["x"][:, None, :])  # commander_node.cpp:492 undone: pos = Rwb (p_b + x)
+    pos = np.where(far[..., None], pos_far, b["swing_pos"].reshape(n, 4, 3))
+    b["swing_pos"] = np.ascontiguousarray(pos.reshape(n, 12))
+    kin = O.default_kinematics()
+    kin.tau_min, kin.tau_max = -1.0e9, 1.0e9
+    ctl = q.BalanceController.from_params(P)
+    ctl.set_kinematics(tau_min=-1.0e9, tau_max=1.0e9)
+    o = ctl.control_batch_host(b, want_torques=True)
+    ref = O.tick_swing_batch(P, b, kin=kin, threads=8)
+    sw = (b["stance"] == 0) & far
+    assert sw.sum() > n // 4
+    tau, rt = o["joint_tau"].reshape(n, 4, 3), ref["joint_tau"].reshape(n, 4, 3)
+    assert np.isfinite(tau[sw]).all()
+    scale = np.maximum(20.0, np.abs(rt).max(axis=-1, keepdims=True))
+    assert np.max(np.abs(tau - rt) / scale) < 1e-6
+    # the pseudo-inverse is what is in there: with the measured state at the IK solution only kd * pinv(J) v remains
+    i, leg = np.argwhere(sw)[0]
+    pbl = R[i].T @ pos[i, leg] - b["x"][i]
+    qr = O.leg_ik(leg, pbl)
+    J = O.leg_jacobian(leg, qr)
+    want = np.array(kin.jc_kp) * 0.0 + np.array(kin.jc_kd) * (np.linalg.pinv(J, rcond=1e-15) @ (R[i].T @ b["swing_vel"].reshape(n, 4, 3)[i, leg])
+                                                             - b["joint_qdot"].reshape(n, 4, 3)[i, leg])
+    wrap = lambda a: (a + np.pi) % (2 * np.pi) - np.pi
+    want = want + np.array(kin.jc_kp) * wrap(np.mod(qr, 2 * np.pi) - np.mod(b["joint_q"].reshape(n, 4, 3)[i, leg], 2 * np.pi))
+    np.testing.assert_allclose(tau[i, leg], want, atol=1e-6 * max(20.0, np.abs(want).max()))
 
 
 @pytest.mark.parametrize("n", [600, 36000, 140000])  # G = 4; G = 2 single fill; G = 2 persistent waves (dense restock)

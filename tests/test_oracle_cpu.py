@@ -193,6 +193,47 @@ def test_swing_torque_composition():
     assert np.max(np.abs(t0["joint_tau"][~st])) < 1e-9
 
 
+def test_singular_leg_jacobian_takes_the_pinv_branch():
+    """legJacobianInverse (kinematics.cpp:190-204): arma::inv, else arma::pinv, else J^T.  A swing reference out of
+    reach makes legInverseKinematics clamp d to 1 (kinematics.cpp:131-134): the knee is straight, J has rank 2 (rank 1
+    when y^2 + z^2 < l1^2 is clamped too, :137-140) and the reference's answer is pinv(J) v.  The oracle's pinv
+    (one-sided Jacobi SVD, Armadillo's tolerance) against numpy.linalg.pinv (LAPACK gesdd), and the swing torque
+    built on it against the formula of joint_controller.cpp:28-36."""
+    rng = np.random.default_rng(12)
+    kin = O.default_kinematics()
+    hip = np.array(kin.hip).reshape(4, 3)
+    seen_rank = set()
+    for trial in range(400):
+        leg = trial % 4
+        direction = rng.normal(size=3)
+        if trial % 5 == 0:
+            direction[1:] *= 0.05  # nearly along x: y^2 + z^2 < l1^2, the second clamp -> rank 1
+        target = hip[leg] + direction / np.linalg.norm(direction) * rng.uniform(0.55, 1.5)  # reach is 0.077 + 0.211 + 0.230
+        q = O.leg_ik(leg, target)
+        assert q[2] == 0.0  # knee straight: atan2(-0, 1)
+        J = O.leg_jacobian(leg, q)
+        sv = np.linalg.svd(J, compute_uv=False)
+        rank = int((sv > 3 * sv[0] * np.finfo(float).eps).sum())
+        assert rank in (1, 2)
+        seen_rank.add(rank)
+        Jp, ok = O.pinv3(J)
+        assert ok
+        ref = np.linalg.pinv(J, rcond=3 * np.finfo(float).eps)
+        np.testing.assert_allclose(Jp, ref, atol=1e-12 * max(1.0, np.abs(ref).max()))
+        vel = rng.normal(size=3)
+        qm, qdm = rng.uniform(-1, 1, 3), rng.uniform(-1, 1, 3)
+        tau = O.swing_torque(leg, np.eye(3), np.zeros(3), target, vel, qm, qdm, kin)
+        wrap = lambda a: (a + np.pi) % (2 * np.pi) - np.pi
+        want = np.array(kin.jc_kp) * wrap(np.mod(q, 2 * np.pi) - np.mod(qm, 2 * np.pi)) + np.array(kin.jc_kd) * (ref @ vel - qdm) + np.array(kin.jc_kff)
+        np.testing.assert_allclose(tau, want, atol=1e-9)
+    assert seen_rank == {1, 2}
+    # a regular configuration still takes arma::inv
+    q = np.array([0.2, 0.7, -1.4])
+    J = O.leg_jacobian(1, q)
+    tau = O.swing_torque(1, np.eye(3), np.zeros(3), O.leg_fk(1, q), np.array([0.3, -0.2, 0.1]), q, np.zeros(3), kin)
+    np.testing.assert_allclose(tau, np.array(kin.jc_kd) * np.linalg.solve(J, [0.3, -0.2, 0.1]), atol=1e-9)
+
+
 def _planned_batch(n, tick, dt=1.0 / 300.0):
     """config-3-like states with a trot gait clock (offsets 0,.5,.5,0; 0.8/0.18) advanced to `tick`."""
     b = W.with_joint_angles(W.config3(n))
