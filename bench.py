@@ -86,7 +86,8 @@ def time_launches(launches, steps, warmup, dist=None):
     import torch
 
     m = len(launches)
-    for i in range(max(warmup, min(m, 8))):  # at least a few sets so that every code path is paged in
+    w = max(warmup, min(m, 8))  # at least a few sets so that every code path is paged in
+    for i in range(w):
         launches[i % m]()
     torch.cuda.synchronize()
     if dist is not None:
@@ -97,7 +98,7 @@ def time_launches(launches, steps, warmup, dist=None):
     t0 = time.perf_counter()
     ev0.record()  # torch's current stream == the stream control_batch launches on
     for i in range(steps):
-        launches[(warmup + i) % m]()
+        launches[(w + i) % m]()  # continues where the warm-up stopped: with K distinct sets the first timed ones were never touched
     ev1.record()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0  # this rank's K steps; the caller takes the MAX over ranks
@@ -206,18 +207,20 @@ def cpu_baseline(P, batch, budget_s=4.0):
     sample = {k: np.ascontiguousarray(np.tile(v[:base], (tile, 1))) for k, v in batch.items()}
     n = base * tile
     c_oracle.set_refine(False)  # time the algorithm, not the checker's long-double recomputation of the accepted point
-    c_oracle.control_batch(P, {k: v[:64] for k, v in sample.items()}, threads=threads)  # warm-up / thread pool
-    t0 = time.perf_counter()
-    c_oracle.control_batch(P, {k: v[:512] for k, v in sample.items()}, threads=1)
-    one = 512 / (time.perf_counter() - t0)
-    reps, t0 = 0, time.perf_counter()
-    while True:
-        c_oracle.control_batch(P, sample, threads=threads)
-        reps += 1
-        if time.perf_counter() - t0 >= budget_s:
-            break
-    dt = time.perf_counter() - t0
-    c_oracle.set_refine(True)
+    try:
+        c_oracle.control_batch(P, {k: v[:64] for k, v in sample.items()}, threads=threads)  # warm-up / thread pool
+        t0 = time.perf_counter()
+        c_oracle.control_batch(P, {k: v[:512] for k, v in sample.items()}, threads=1)
+        one = 512 / (time.perf_counter() - t0)
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            c_oracle.control_batch(P, sample, threads=threads)
+            reps += 1
+            if time.perf_counter() - t0 >= budget_s:
+                break
+        dt = time.perf_counter() - t0
+    finally:
+        c_oracle.set_refine(True)  # the checker's mode, whatever happened above
     literal = None
     try:  # the literal reference sequence (qpOASES init -> hotstart), only where qpOASES itself is installed
         from oracle.qpoases_ref import run as qref
@@ -313,10 +316,31 @@ def pmc_traffic(cfg, n, sha, kernel):
             bl = d.get("bench_line", {})
             if (bl.get("config", {}).get("robots_per_gpu") == n and bl.get("config", {}).get("kernel") == kernel
                     and bl.get("kernel_src_sha16") == sha and "traffic" in d):
-                best = (d["traffic"]["hbm_bytes_per_launch"], os.path.relpath(f, ROOT))
+                best = (d["traffic"]["hbm_bytes_per_launch"], os.path.relpath(f, ROOT), d.get("valu"))
         except Exception:
             pass
     return best
+
+
+def attach_pmc(target, cfg, n, sha, kernel):
+    """roofline.traffic / roofline_valu of `target` (a bench line or an other_configs entry) from the committed,
+    hash-matched PMC pass of that workload.  The HBM fraction is what the contract asks for; the bound that binds the
+    solve is FP64 VALU issue, so that one travels next to it."""
+    tr = pmc_traffic(cfg, n, sha, kernel)
+    if tr is None:
+        return
+    src = tr[1] + " (rocprofv3 --pmc passes of this workload on these kernel sources)"
+    if "roofline" in target:
+        target["roofline"]["traffic"] = tr[0]
+        target["roofline"]["traffic_source"] = src
+    else:
+        target["hbm_traffic_bytes_per_launch"] = tr[0]
+    if tr[2]:
+        v = tr[2]
+        target["roofline_valu"] = {"bound": "fp64-valu-issue", "insts_valu_per_launch": v["insts_valu_per_launch"],
+                                   "insts_valu_per_robot": v["insts_valu_per_robot"], "issue_frac": v["issue_frac"],
+                                   "how": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x kernel time x 2.4 GHz), kernel time of the profiled run",
+                                   "source": src}
 
 
 def rates(r, key, n, steps, bytes_per):
@@ -384,14 +408,32 @@ def main():
     if world > 1 or os.environ.get("QC_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist_mod
 
+        import datetime
+
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if one_dev:
-            local_rank = 0
-            dist_mod.init_process_group("gloo")
-        else:
+        # Fail fast and readably: a rank that never joins (or a collective that never completes) ends every rank with a
+        # one-line diagnostic after QC_BENCH_TIMEOUT_S (default 60 s) instead of RCCL's silent ten-minute wait.
+        limit = float(os.environ.get("QC_BENCH_TIMEOUT_S", "60"))
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+        backend = "gloo" if (one_dev and os.environ.get("QC_BENCH_ONE_DEVICE_BACKEND", "gloo") == "gloo") else "nccl"
+        try:
+            if one_dev:
+                local_rank = 0  # test hook: every rank on cuda:0 (gloo; "nccl" where RCCL accepts two ranks per device)
             torch.cuda.set_device(local_rank)
-            dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            kw = {} if backend == "gloo" else {"device_id": torch.device("cuda", local_rank)}
+            dist_mod.init_process_group(backend, timeout=datetime.timedelta(seconds=limit), **kw)
+            probe = torch.ones(1, device=f"cuda:{local_rank}") if backend == "nccl" else torch.ones(1)
+            dist_mod.all_reduce(probe)  # the first collective builds the communicator: do it here, under the same watch
+            if backend == "nccl":
+                torch.cuda.synchronize()
+            if int(probe.item()) != world:
+                raise RuntimeError(f"first all-reduce saw {int(probe.item())} of {world} ranks")
+        except Exception as e:  # noqa: BLE001 - whatever went wrong, say which rank and where it was waiting
+            print(f"bench.py: rank {rank}/{world} (local GPU {local_rank}, backend {backend}, master "
+                  f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}): the process group did not form within "
+                  f"{limit:.0f} s - {type(e).__name__}: {str(e).splitlines()[0] if str(e) else ''}", file=sys.stderr, flush=True)
+            os._exit(3)
         dist = dist_mod
     device = local_rank if dist is not None else 0
     torch.cuda.set_device(device)
@@ -419,6 +461,9 @@ def main():
     rdev = f"cuda:{device}" if on_gpu else None
     wall, solved_total, total_robots = reduce_counters(dist, res["cold"][0], res["solved"], n, device=rdev)
     wall_warm, _, _ = reduce_counters(dist, res["warm_cache"][0], 0, 0, device=rdev)
+    from quadruped_control_amd.sharding import reduce_rank_stats
+
+    k_min, k_max, allreduce_s = reduce_rank_stats(dist, res["cold"][1] / args.steps * 1e6, device=rdev)
 
     gather_s = None
     if dist is not None and args.gather_results:
@@ -443,7 +488,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": wall / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": scaling,
+            "scaling": scaling if world > 1 else None,  # no scaling claim on a one-GPU line (the key stays for the contract's parsers)
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic" + (" (generated on the device, per shard)" if cfg in (3, 5) else ""),
@@ -465,24 +510,33 @@ def main():
                          "avg_kernel_us": kernel_s * 1e6,
                          "note": "cold-cache protocol; latency / FP64-VALU bound active-set solve, see DESIGN.md 4"},
         }
+        if res["warm"]:
+            line["roofline"]["bytes_per_robot"] = ("496 = 388 read + 4 warm-start word read + 100 written + 4 active-set word written; SURVEY 8d's 592 "
+                                                   "also counts a 96-byte warm primal, which this solver does not read (it restarts from the active set alone)")
         if res["solved_all_sets"] != res["sets"] * n:
             line["solved_fraction_all_sets"] = res["solved_all_sets"] / (res["sets"] * n)
         if gather_s is not None:
             line["result_gather"] = {"bytes_per_rank": n * 96, "seconds": gather_s, "GBs_per_rank": n * 96 * (world - 1) / gather_s / 1e9,
                                      "what": "all-gather of the [n, 12] GRF blocks after the timed region (not part of value)"}
-        tr = pmc_traffic(cfg, n, sha, ctl.kernel_name)
-        if tr is not None:
-            line["roofline"]["traffic"] = tr[0]
-            line["roofline"]["traffic_source"] = tr[1] + " (rocprofv3 --pmc passes of this command on these kernel sources)"
-        if world > 1 and scaling == "strong" and not args.no_sweep:
-            # the N = 1 point of this strong-scaling curve, measured in the same run on rank 0's GPU while the other
-            # ranks wait at the final barrier: the WHOLE batch on one device (efficiency = value / (N x this value))
+        attach_pmc(line, cfg, n, sha, ctl.kernel_name)
+        if dist is not None:
+            line["ranks"] = {"avg_kernel_us_min": k_min, "avg_kernel_us_max": k_max,
+                             "allreduce_us": allreduce_s * 1e6, "backend": dist.get_backend(),
+                             "what": "slowest / fastest rank's average kernel time (HIP events); one 8-byte all-reduce of the kind that "
+                                     "brackets the timed region (barrier + counter reduction are the only collectives: no data-path exchange)"}
+        if world > 1 and scaling == "strong":
+            # the N = 1 point of this strong-scaling curve, ALWAYS measured in the same run on rank 0's GPU while the other
+            # ranks wait at the final barrier: the WHOLE batch on one device, so that the line explains itself
             del res
             torch.cuda.empty_cache()
             r1 = run_config(ctl, q, cfg, total_robots, 0, 10, 10, None, device, protocols=("cold",))
             line["n1_reference"] = {"robots": total_robots, "value": total_robots * 10 / r1["cold"][0], "avg_kernel_us": r1["cold"][1] / 10 * 1e6,
                                     "solved_fraction": r1["solved"] / total_robots,
                                     "what": "the whole batch on rank 0's GPU alone, after the timed region (not part of value)"}
+            line["scaling_efficiency"] = line["value"] / (world * line["n1_reference"]["value"])
+            line["scaling_note"] = ("strong scaling of BASELINE.json configs[4]: the same 2,097,152 robots on N GPUs; efficiency = value / "
+                                    "(N x n1_reference.value).  A one-GPU line of `bench.py` without --config measures configs[1] (4096 robots) "
+                                    "and is NOT the N = 1 point of this curve; n1_reference (or other_configs.config5_n1 of that line) is.")
             res = {"batch": None}
             del r1
         if world == 1 and not args.no_cpu_baseline:
@@ -499,6 +553,7 @@ def main():
                 bp = BYTES_PER_ROBOT_WARM if r["warm"] else BYTES_PER_ROBOT_COLD
                 other[f"config{c}"] = {"robots": CONFIG_N[c], "solved_fraction": r["solved_all_sets"] / (r["sets"] * CONFIG_N[c]), "sets": r["sets"],
                                        "cold_cache": rates(r, "cold", CONFIG_N[c], k, bp), "warm_cache": rates(r, "warm_cache", CONFIG_N[c], k, bp)}
+                attach_pmc(other[f"config{c}"], c, CONFIG_N[c], sha, ctl.kernel_name)
                 del r
                 torch.cuda.empty_cache()
             # the N = 1 point of the config-5 scaling curve: the full 2,097,152-robot batch on this GPU (1 GB: cold by size)

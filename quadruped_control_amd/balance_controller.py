@@ -201,15 +201,20 @@ class BalanceController:
                 raise ValueError("swing_state: need a contiguous uint8 tensor of n * 224 bytes on the device")
             bi.swing_state = ss.data_ptr()
         if out is None:
-            out = {"grf_body": torch.empty((n, 12), dtype=torch.float64, device=dev),
-                   "status": torch.empty((n,), dtype=torch.int32, device=dev)}
+            # Allocated here: defined contents until the first launch has run (plan_batch launches nothing) - zero forces and
+            # status -1 ("not computed yet", no QC_* code), never uninitialised memory.
+            out = {"grf_body": torch.zeros((n, 12), dtype=torch.float64, device=dev),
+                   "status": torch.full((n,), -1, dtype=torch.int32, device=dev)}
             if want_active_set:
-                out["active_set"] = torch.empty((n,), dtype=torch.int32, device=dev)
+                out["active_set"] = torch.zeros((n,), dtype=torch.int32, device=dev)
             if want_iterations:
-                out["iterations"] = torch.empty((n,), dtype=torch.int32, device=dev)
+                out["iterations"] = torch.zeros((n,), dtype=torch.int32, device=dev)
             if want_torques:
-                out["joint_tau"] = torch.empty((n, 12), dtype=torch.float64, device=dev)
+                out["joint_tau"] = torch.zeros((n, 12), dtype=torch.float64, device=dev)
         else:
+            for flag, name in ((want_active_set, "active_set"), (want_iterations, "iterations"), (want_torques, "joint_tau")):
+                if flag and out.get(name) is None:
+                    raise ValueError(f"out: '{name}' was asked for (want_{'torques' if name == 'joint_tau' else name}=True) but the supplied `out` has no such tensor")
             for name, shape, dt in (("grf_body", n * 12, torch.float64), ("status", n, torch.int32), ("active_set", n, torch.int32),
                                     ("iterations", n, torch.int32), ("joint_tau", n * 12, torch.float64)):
                 t = out.get(name)

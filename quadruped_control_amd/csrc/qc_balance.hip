@@ -124,6 +124,16 @@ struct Lane {
   // the same f^ from the same working set (idempotent), so only what must not move once it has finished -
   // working set, status, iteration count - is held back by `live`, instead of copying the whole lane state
   // and selecting it back.  Callers whose EXEC mask already excludes finished robots pass true.
+  // What makes that sound (the invariants behind `live`):
+  //  * a SOLVED robot is a fixed point: the same working set gives the same f^ bit for bit, no face blocks (every
+  //    candidate is +BIG, alpha clamps to 1, beta = 0), so f = f^ is rewritten with the value it already holds;
+  //  * a robot that is finished WITHOUT being solved (QC_NOT_PD, the iteration cap, a racing group whose partner won)
+  //    does keep moving f while C stays frozen - and nobody reads that f: store_result() writes zero forces for every
+  //    status other than QC_SOLVED, and a racing loser never pushes (the winner's group does);
+  //  * the cap needs no per-lane bookkeeping: robots of one fill start together and `iters` counts wave-uniform
+  //    recalculations, so all of them reach max_iter in the same recalculation and the loop ends there.
+  // tests/test_gpu_matrix.py::test_iteration_cap_and_bad_inputs_agree_across_widths holds status, iteration count and the
+  // (zero) forces of capped / bad robots equal across the lane-group widths.
   enum { MIXED = 0, FIRST = 1, STEADY = 2 };
   template <int PHASE = MIXED, class PT>
   QC_DEV bool iterate(const PT& P, Eqp& eqp, const bool live = true) {
@@ -363,14 +373,15 @@ QC_DEV void swing_plan(CParams& P, const BatchIn& in, long robot, int foot0, uin
 
 // the assembly of one robot (or of this lane's feet of it): wrench target and lever arms, contact state, optional
 // gait clock and swing planning.  Returns the stance word (bits 0-3 LegState, bit 8 = non-finite input).
+// (`S`, `fp`: what fetch_state() read; `sw`: the robot's four LegState bytes if in.stance is given)
 template <bool KIN, int FPL, bool STR>
-QC_DEV uint32_t assemble_robot(CParams& P, const BatchIn& in, long robot, int member, Wrench<FPL>& W) {
+QC_DEV uint32_t assemble_from_state(CParams& P, const BatchIn& in, long robot, int member, const RawState& S, const double (&fp)[3 * FPL], uint32_t sw,
+                                    Wrench<FPL>& W) {
   constexpr int GG = 4 / FPL;
   const int foot0 = member * FPL;
-  const double fin = build_wrench<FPL, KIN>(P, in, robot, foot0, W);
+  const double fin = wrench_from_state<FPL, KIN>(P, S, fp, foot0, W);
   uint32_t stance = 0xFu;  // make_stance_gait(), gait.cpp:24-34
   if (in.stance) {
-    const uint32_t sw = *reinterpret_cast<const uint32_t*>(in.stance + 4 * robot);
     stance = ((sw & 0xFFu) ? 1u : 0u) | ((sw & 0xFF00u) ? 2u : 0u) | ((sw & 0xFF0000u) ? 4u : 0u) | ((sw & 0xFF000000u) ? 8u : 0u);
   } else if (in.gait_phase) {
     // GaitScheduler::phase(), gait.cpp:125-134 (almost_equal = |a-b| < 1e-12, math/numerics.cpp:18-21)
@@ -411,6 +422,17 @@ QC_DEV uint32_t assemble_robot(CParams& P, const BatchIn& in, long robot, int me
   return stance;
 }
 
+template <bool KIN, int FPL, bool STR>
+QC_DEV uint32_t assemble_robot(CParams& P, const BatchIn& in, long robot, int member, Wrench<FPL>& W) {
+  // all loads first, back to back (see the one-lane fill in balance_kernel): one memory round trip instead of four
+  const uint32_t sw = in.stance ? *reinterpret_cast<const uint32_t*>(in.stance + 4 * robot) : 0u;
+  RawState S;
+  double fp[3 * FPL];
+  fetch_state<FPL, KIN>(in, robot, member * FPL, S, fp);
+  asm volatile("" ::: "memory");
+  return assemble_from_state<KIN, FPL, STR>(P, in, robot, member, S, fp, sw, W);
+}
+
 // FPL = 4: one lane assembles a whole robot (dense restock of a big batch);
 // FPL = 4/G: the G lanes of a group share a robot, each doing its own feet
 // (small fills, where latency matters more than lane efficiency).
@@ -419,8 +441,8 @@ QC_DEV void assemble_to_stock(CParams& P, const BatchIn& in, const uint32_t* __r
                               double* __restrict__ sin) {
   Wrench<FPL> W;
   const int foot0 = member * FPL;
+  const uint32_t wv = warm ? warm[robot] : 0u;  // (issued with the robot's other loads, not behind the assembly)
   const uint32_t stance = assemble_robot<KIN, FPL, STR>(P, in, robot, member, W);
-  const uint32_t wv = warm ? warm[robot] : 0u;
 #pragma unroll
   for (int i = 0; i < FPL; i++)
 #pragma unroll
@@ -435,14 +457,16 @@ QC_DEV void assemble_to_stock(CParams& P, const BatchIn& in, const uint32_t* __r
 
 // output transform, BC.cpp:218-232: fb = -Rwb^T fw for stance legs; optional torque map.  `fw` = world-frame forces of
 // the FPL feet from foot0 on; `member` 0 also writes the per-robot words.
+// `Rl` != nullptr: the robot's Rwb is parked in LDS (entry k at Rl[k * rstride]) by the wave's assembly phase - the one-lane
+// one-fill kernel keeps it there instead of reading the 72-byte row from global memory a second time.
 template <bool KIN, int FPL>
 QC_DEV void store_result(CParams& P, const BatchIn& in, const BatchOut& out, long idx, uint32_t stance, int status, int iters, uint32_t word,
-                         const double (&fw)[3 * FPL], int member) {
+                         const double (&fw)[3 * FPL], int member, const double* __restrict__ Rl = nullptr, int rstride = 0) {
   const int foot0 = member * FPL;
   const double* Rp = in.Rwb + 9 * idx;
   double R[9];
 #pragma unroll
-  for (int k = 0; k < 9; k++) R[k] = Rp[k];
+  for (int k = 0; k < 9; k++) R[k] = Rl ? Rl[k * rstride] : Rp[k];
   const int st_out = (stance & 0x100u) ? (int)QC_NOT_PD : status;
   double* o = out.grf_body + 12 * idx + 3 * foot0;
 #pragma unroll
@@ -515,7 +539,8 @@ QC_DEV void store_result(CParams& P, const BatchIn& in, const BatchOut& out, lon
 }
 
 template <bool KIN, int FPL, int SP>
-QC_DEV void store_from_stock(CParams& P, const BatchIn& in, const BatchOut& out, const double* __restrict__ sout, int slot, int member) {
+QC_DEV void store_from_stock(CParams& P, const BatchIn& in, const BatchOut& out, const double* __restrict__ sout, int slot, int member,
+                             const double* __restrict__ Rl = nullptr) {
   const int foot0 = member * FPL;
   const long idx = __double_as_longlong(sout[OUT_IDX * SP + slot]);
   const unsigned long long sw = (unsigned long long)__double_as_longlong(sout[OUT_STAT * SP + slot]);
@@ -523,7 +548,7 @@ QC_DEV void store_from_stock(CParams& P, const BatchIn& in, const BatchOut& out,
   double fw[3 * FPL];
 #pragma unroll
   for (int k = 0; k < 3 * FPL; k++) fw[k] = sout[(OUT_F + 3 * foot0 + k) * SP + slot];
-  store_result<KIN, FPL>(P, in, out, idx, (uint32_t)(ww >> 32), (int)(uint32_t)sw, (int)(uint32_t)(sw >> 32), (uint32_t)ww, fw, member);
+  store_result<KIN, FPL>(P, in, out, idx, (uint32_t)(ww >> 32), (int)(uint32_t)sw, (int)(uint32_t)(sw >> 32), (uint32_t)ww, fw, member, Rl, SP);
 }
 
 // dense assembly of the next (up to 64) robots of the chunk into the input stock; returns how many
@@ -548,7 +573,8 @@ QC_DEV int restock(const DevParams* __restrict__ Pg, const BatchIn& in, const ui
 
 // store the robots parked in the output stock: one per lane, or one per lane group when there are few
 template <int G, bool KIN, bool STR, int SP>
-QC_DEV void flush_out(const DevParams* __restrict__ Pg, const BatchIn& in, const BatchOut& out, const double* __restrict__ sout, int out_n, int lane) {
+QC_DEV void flush_out(const DevParams* __restrict__ Pg, const BatchIn& in, const BatchOut& out, const double* __restrict__ sout, int out_n, int lane,
+                      const double* __restrict__ Rplanes = nullptr) {
   if (G > 1 && out_n <= 64 / G) {
     const int grp = lane_group<G, STR>(lane);
     if (grp < out_n) {
@@ -557,7 +583,7 @@ QC_DEV void flush_out(const DevParams* __restrict__ Pg, const BatchIn& in, const
     }
   } else if (lane < out_n) {
     CParams& P = *QC_PARAMS_HERE(Pg);
-    store_from_stock<KIN, 4, SP>(P, in, out, sout, lane, 0);
+    store_from_stock<KIN, 4, SP>(P, in, out, sout, lane, 0, Rplanes ? Rplanes + lane : nullptr);
   }
 }
 
@@ -764,7 +790,39 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
     if (cursor >= end) return;
     UConst uc;  // RESIDENT: the recalculation's constants live in VGPRs (no scalar load + wait per recalculation)
     if constexpr (RESIDENT) uc = load_uconst(*QC_PARAMS_HERE(Pg));
-    stock_n = restock<G, KIN, STR, SP>(Pg, in, warm, cursor, end, lane, member, sin);
+    // One lane per robot: the lane that assembles a robot is the lane that solves it, so the robot goes straight from the
+    // assembly into the solver's registers - no input stock, no barrier - and its Rwb is parked in the first nine planes of
+    // the (otherwise idle) input-stock area for the output transform; the planes behind them serve as the re-pack area of the tail.
+    constexpr bool DIRECT = G == 1;
+    constexpr int R_PLANES = DIRECT ? 9 : 0;
+    static_assert(!DIRECT || (R_PLANES * SP + 16 * REPACK_RS <= IN_PLANES * SP), "Rwb planes + re-pack records fit the input-stock area");
+    if constexpr (DIRECT) {
+      const long left = end - cursor;
+      stock_n = left < 64 ? (int)left : 64;
+      if (lane < stock_n) {
+        // Everything the fill reads from memory is issued back to back - the contact bytes and the warm-start word first
+        // (behind wave-uniform null tests), then the 48 doubles of the state - and nothing dependent sits in between: a
+        // wave's fill used to chain four to five vector-memory round trips (two batches of state, contact bytes, warm word,
+        // Rwb again: 2.5 us from kernel entry to "inputs landed" for a lone wave, profiles/r03_timeline.log).
+        const BatchIn& ia = in;
+        const uint32_t* wp = warm;
+        const long robot = cursor + lane;
+        const uint32_t sw = ia.stance ? *reinterpret_cast<const uint32_t*>(ia.stance + 4 * robot) : 0u;
+        const uint32_t wv = wp ? wp[robot] : 0u;
+        RawState S;
+        double fp[12];
+        fetch_state<4, KIN>(ia, robot, 0, S, fp);
+        asm volatile("" ::: "memory");  // (the loads above stay above)
+        CParams& P = *QC_PARAMS_HERE(Pg);
+        Wrench<4> W;
+        const uint32_t st = assemble_from_state<KIN, 4, false>(P, ia, robot, 0, S, fp, sw, W);
+#pragma unroll
+        for (int k = 0; k < 9; k++) sin[k * SP + lane] = S.R[k];
+        L.load_direct(W, st, wv, robot, 0);
+      }
+    } else {
+      stock_n = restock<G, KIN, STR, SP>(Pg, in, warm, cursor, end, lane, member, sin);
+    }
     const int grp = lane_group<G, STR>(lane);
     busy = grp < stock_n;
     // measurement probe (qc_set_tuning "probe_batch_load"): load -> assemble -> store only, no recalculation
@@ -866,7 +924,7 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
       return;
     }
     if (busy) {
-      L.template load_from_stock<SP>(sin, grp, member);
+      if constexpr (!DIRECT) L.template load_from_stock<SP>(sin, grp, member);
       eqp.setup(*QC_PARAMS_HERE(Pg), L.Wr, L.foot0);
     }
     const bool mine = busy;
@@ -893,7 +951,7 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
         bm = __builtin_amdgcn_ballot_w64(busy);
       }
       if (!busy && mine) L.template push_result<SP>(sout, grp);  // finished in the two-lane layout
-      finish_on_four_lanes<KIN, Eqp::kUniform, SP>(Pg, L, busy, bm, grp, member, lane, sin, sout, warm == nullptr);
+      finish_on_four_lanes<KIN, Eqp::kUniform, SP>(Pg, L, busy, bm, grp, member, lane, sin + R_PLANES * SP, sout, warm == nullptr);
     } else {
       while (busy) {
         if constexpr (RESIDENT) {
@@ -907,7 +965,7 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
     }
     QC_CLK(7, 8);
     __syncthreads();
-    flush_out<Eqp::G, KIN, STR, SP>(Pg, in, out, sout, stock_n, lane);
+    flush_out<Eqp::G, KIN, STR, SP>(Pg, in, out, sout, stock_n, lane, DIRECT ? sin : nullptr);
     QC_CLK_END(8);
     return;
   }
@@ -988,6 +1046,10 @@ struct qc_handle {
   qc::DevParams* d_params;  // device copy of dp (rewritten only by the qc_set_* calls, after a device synchronise)
   bool diag_w;   // W diagonal -> 6x6 formulation
   bool uniform;  // additionally S diagonal and W = w*I -> scalar-constant specialisation
+  // what qc_create was given: the tuning overrides (force_general / force_dense / max_iter / probe_batch_load) restore from these
+  bool cfg_diag_w, cfg_uniform;
+  int cfg_max_iter;
+  bool force_general, force_dense, probing;
   // launch heuristics (defaults from measurements; qc_set_tuning overrides them)
   int refill_t;            // parked lanes that trigger a refill (persistent waves)
   double rounds_cold;      // cold batches up to rounds x (robots resident as one-fill workgroups) run one-fill
@@ -1102,6 +1164,15 @@ static int upload_params(qc_handle* h) {
 // persistent waves), so `rounds` is unbounded for the 6x6 forms and the persistent kernels (waves walking
 // contiguous chunks with lane refill) serve the one-lane dense form and qc_set_tuning("one_fill", 0).
 enum { QC_FORM_UNIFORM = 0, QC_FORM_GENERAL = 1, QC_FORM_DENSE = 2 };
+// The persistent-wave (MODE 0) kernels of the 6x6 forms - round 1's large-batch kernels, which the planner has not picked
+// for any batch since the one-lane one-fill kernel exists - are compiled only into development builds
+// (-DQC_PERSISTENT_6X6=1: tools/build_dev.sh, the A/B scans, QC_TEST_PERSISTENT_6X6=1 in tests/test_gpu_matrix.py): twelve
+// instantiations with up to 672 B of scratch per lane that a default handle can never launch.  Without them the 6x6
+// forms always run as one-fill workgroups and qc_set_tuning("one_fill", 0) / chunks beyond one fill apply to the dense
+// form only (whose one-lane kernel still walks chunks beyond one round of workgroups).
+#ifndef QC_PERSISTENT_6X6
+#define QC_PERSISTENT_6X6 0
+#endif
 #ifndef QC_ROUNDS_COLD
 #define QC_ROUNDS_COLD 1.0e9
 #endif
@@ -1126,18 +1197,24 @@ static qc_kernel_fn kernel_for(int form, int G, int mode, bool kin, int minw = 2
   (void)minw;
   if (form == QC_FORM_DENSE && G == 4) return race == 4 ? kernel_of<EqpDense4, 1, 1, 4>(kin) : (race == 2 ? kernel_of<EqpDense4, 1, 1, 2>(kin) : kernel_of<EqpDense4, 1, 1>(kin));
   if (form == QC_FORM_DENSE) return mode ? kernel_of<EqpDense, 1, 1>(kin) : kernel_of<EqpDense, 1, 0>(kin);
+#if QC_PERSISTENT_6X6
+#define QC_MODE0(EQP) kernel_of<EQP, 2, 0>(kin)
+#else
+#define QC_MODE0(EQP) nullptr /* the planner never asks: plan_launch keeps the 6x6 forms on one-fill workgroups */
+#endif
   if (form == QC_FORM_GENERAL) {
     if (G == 4 && mode && STR && race == 4) return kernel_of<EqpDiagW<false, 4, STR>, 2, 1, (STR ? 4 : 1)>(kin);
     if (G == 4 && mode && STR && race == 2) return kernel_of<EqpDiagW<false, 4, STR>, 2, 1, (STR ? 2 : 1)>(kin);
-    if (G == 4) return mode ? kernel_of<EqpDiagW<false, 4, STR>, 2, 1>(kin) : kernel_of<EqpDiagW<false, 4>, 2, 0>(kin);
-    if (G == 2) return mode ? kernel_of<EqpDiagW<false, 2>, 2, 1>(kin) : kernel_of<EqpDiagW<false, 2>, 2, 0>(kin);
-    return mode ? kernel_of<EqpDiagW<false, 1>, 2, 1>(kin) : kernel_of<EqpDiagW<false, 1>, 2, 0>(kin);
+    if (G == 4) return mode ? kernel_of<EqpDiagW<false, 4, STR>, 2, 1>(kin) : QC_MODE0(QC_COMMA(EqpDiagW<false, 4>));
+    if (G == 2) return mode ? kernel_of<EqpDiagW<false, 2>, 2, 1>(kin) : QC_MODE0(QC_COMMA(EqpDiagW<false, 2>));
+    return mode ? kernel_of<EqpDiagW<false, 1>, 2, 1>(kin) : QC_MODE0(QC_COMMA(EqpDiagW<false, 1>));
   }
   if (G == 4 && mode == 2 && STR && race == 4) return kernel_of<EqpDiagW<true, 4, STR>, 2, 2, (STR ? 4 : 1)>(kin);
   if (G == 4 && mode == 2 && STR && race == 2) return kernel_of<EqpDiagW<true, 4, STR>, 2, 2, (STR ? 2 : 1)>(kin);
-  if (G == 4) return mode == 2 ? kernel_of<EqpDiagW<true, 4, STR>, 2, 2>(kin) : (mode ? kernel_of<EqpDiagW<true, 4, STR>, 2, 1>(kin) : kernel_of<EqpDiagW<true, 4>, 2, 0>(kin));
-  if (G == 2) return mode ? kernel_of<EqpDiagW<true, 2>, 2, 1>(kin) : kernel_of<EqpDiagW<true, 2>, 2, 0>(kin);
-  return mode ? kernel_of<EqpDiagW<true, 1>, 2, 1>(kin) : kernel_of<EqpDiagW<true, 1>, 2, 0>(kin);
+  if (G == 4) return mode == 2 ? kernel_of<EqpDiagW<true, 4, STR>, 2, 2>(kin) : (mode ? kernel_of<EqpDiagW<true, 4, STR>, 2, 1>(kin) : QC_MODE0(QC_COMMA(EqpDiagW<true, 4>)));
+  if (G == 2) return mode ? kernel_of<EqpDiagW<true, 2>, 2, 1>(kin) : QC_MODE0(QC_COMMA(EqpDiagW<true, 2>));
+  return mode ? kernel_of<EqpDiagW<true, 1>, 2, 1>(kin) : QC_MODE0(QC_COMMA(EqpDiagW<true, 1>));
+#undef QC_MODE0
 }
 static size_t lds_for(int form, int G, int mode) {
 
@@ -1199,11 +1276,12 @@ static int plan_launch(qc_handle* h, long n, bool kin, bool warm, qc_launch_plan
     if (h->one_fill_override >= 0) one_fill = h->one_fill_override != 0;
     if (h->chunk_override > 0) one_fill = h->chunk_override <= rpw;
     if (form == QC_FORM_DENSE && G == 4) one_fill = true;
+    if (!QC_PERSISTENT_6X6 && form != QC_FORM_DENSE) one_fill = true;  // (the persistent 6x6 kernels are not in this build)
   }
   int mode = 0, race = 1;
   long chunk;
   if (one_fill) {
-    chunk = h->chunk_override > 0 ? h->chunk_override : rpw;
+    chunk = (h->chunk_override > 0 && h->chunk_override <= rpw) ? h->chunk_override : rpw;
     const long blocks = (n + chunk - 1) / chunk;
     // one wave per SIMD is enough: the recalculation's constants stay resident in VGPRs (uniform G = 4 form)
     mode = (form == QC_FORM_UNIFORM && G == 4 && blocks <= (long)h->cus * 4) ? 2 : 1;
@@ -1363,6 +1441,9 @@ int qc_create(const qc_params* p, int device, qc_handle** out) {
   for (int i = 1; i < 12; i++)
     if (p->W[12 * i + i] != p->W[0]) uni = false;
   h->uniform = uni;
+  h->cfg_diag_w = diag;
+  h->cfg_uniform = uni;
+  h->force_general = h->force_dense = h->probing = false;
   for (int i = 0; i < 6; i++) d.Vd[i] = d.V[6 * i + i];
   d.w_u = p->W[0];
   d.inv_w_u = 1.0 / p->W[0];
@@ -1397,6 +1478,7 @@ int qc_create(const qc_params* p, int device, qc_handle** out) {
   // and change neither the recalculation counts of 1 M robots nor anything else measurable).
   d.tol_d = 1e-14;
   d.max_iter = p->max_iter > 0 ? p->max_iter : 200;
+  h->cfg_max_iter = d.max_iter;
   d.clamp_steps = 0;  // 0: per kernel (clamp_steps_for)
   d.tail_race = 1;
   hipDeviceProp_t prop;
@@ -1441,26 +1523,22 @@ int qc_set_tuning(qc_handle* h, const char* key, double value) {
   else if (k == "refill_t") h->refill_t = value > 0 ? (int)value : 16;
   else if (k == "rounds_cold") h->rounds_cold = value;
   else if (k == "rounds_warm") h->rounds_warm = value;
-  else if (k == "force_general") {  // general 6x6 form on uniform weights (same minimiser)
-    bool uni = h->diag_w;
-    for (int i = 0; i < 6; i++)
-      for (int j = 0; j < 6; j++)
-        if (i != j && h->dp.S[6 * i + j] != 0.0) uni = false;
-    for (int i = 1; i < 12; i++)
-      if (h->dp.w[i] != h->dp.w[0]) uni = false;
-    h->uniform = value != 0 ? false : uni;
-  } else if (k == "force_dense") {  // dense 12x12 form on a diagonal W (same minimiser)
-    bool diag = true;
-    for (int i = 0; i < 12; i++)
-      for (int j = 0; j < 12; j++)
-        if (i != j && h->dp.W[12 * i + j] != 0.0) diag = false;
-    h->diag_w = value != 0 ? false : diag;
+  else if (k == "force_general" || k == "force_dense") {
+    // general 6x6 form on uniform weights / dense 12x12 form on a diagonal W (same minimiser).  The form follows from what
+    // qc_create was given and the two flags, in one place, whatever the order of the calls.
+    (k == "force_general" ? h->force_general : h->force_dense) = value != 0;
+    h->diag_w = h->cfg_diag_w && !h->force_dense;
+    h->uniform = h->cfg_uniform && !h->force_general;
   } else if (k == "tol_d") { h->dp.tol_d = value; params = true; }
-  else if (k == "max_iter") { h->dp.max_iter = value > 0 ? (int)value : 200; params = true; }
+  else if (k == "max_iter") {  // <= 0: back to the handle's own cap (qc_params.max_iter)
+    h->probing = false;
+    h->dp.max_iter = value > 0 ? (int)value : h->cfg_max_iter; params = true;
+  }
   else if (k == "clamp_steps") { h->dp.clamp_steps = value >= 1 ? (int)value : 0; params = true; }
   else if (k == "probe_batch_load") {
-    // measurement probe: load -> assemble -> store only (every robot reports QC_MAX_ITER); value 0 restores 200
-    h->dp.max_iter = value != 0 ? 0 : 200; params = true;
+    // measurement probe: load -> assemble -> store only (every robot reports QC_MAX_ITER); 0 restores the handle's own cap
+    h->probing = value != 0;
+    h->dp.max_iter = h->probing ? 0 : h->cfg_max_iter; params = true;
   } else return fail(QC_ERR_INVALID, "qc_set_tuning: unknown key '" + k + "'");
   return params ? upload_params(h) : QC_OK;
 }

@@ -307,48 +307,35 @@ QC_DEV double rcp_nr(double d) {
 
 // Rotation3d(mat).angleAxisTotal(): math/rigid3d.cpp:177-179,198-203
 // (Drake RotationMatrix::ToAngleAxis -> Eigen matrix->quaternion->angle-axis).
+// Eigen's four cases (trace > 0, else pivot on the largest diagonal entry; ties keep the lower index, as its > tests do)
+// differ only in WHICH of d = 1 +- m00 +- m11 +- m22 goes under the square root and where the entries land, so the case is
+// decided first and there is ONE root: r = rsqrt(d) gives sqrt(d) = d r and 0.5 / sqrt(d) = r / 2 without a division, the
+// quaternion entries are selects over six products, and the axis scale angle / +-|q_v| is angle * rsqrt(|q_v|^2).  Written
+// as four branches (round 2) the compiler if-converted all of them: 4 square roots + 5 divisions, 396 instructions against
+// 238 (tools/isa of a one-function kernel); same values to the last ulp or two.
 QC_DEV void angle_axis_total(const double (&m)[9], double (&out)[3]) {
-  double qx, qy, qz, qw;
-  double t = m[0] + m[4] + m[8];
-  if (t > 0.0) {
-    t = sqrt(t + 1.0);
-    qw = 0.5 * t;
-    t = 0.5 / t;
-    qx = (m[7] - m[5]) * t;
-    qy = (m[2] - m[6]) * t;
-    qz = (m[3] - m[1]) * t;
-  } else if (m[0] >= m[4] && m[0] >= m[8]) {  // i = 0 (ties keep the lower index, as Eigen's > tests do)
-    t = sqrt(m[0] - m[4] - m[8] + 1.0);
-    qx = 0.5 * t;
-    t = 0.5 / t;
-    qw = (m[7] - m[5]) * t;
-    qy = (m[3] + m[1]) * t;
-    qz = (m[6] + m[2]) * t;
-  } else if (m[4] >= m[8]) {  // i = 1
-    t = sqrt(m[4] - m[8] - m[0] + 1.0);
-    qy = 0.5 * t;
-    t = 0.5 / t;
-    qw = (m[2] - m[6]) * t;
-    qz = (m[7] + m[5]) * t;
-    qx = (m[1] + m[3]) * t;
-  } else {  // i = 2
-    t = sqrt(m[8] - m[0] - m[4] + 1.0);
-    qz = 0.5 * t;
-    t = 0.5 / t;
-    qw = (m[3] - m[1]) * t;
-    qx = (m[2] + m[6]) * t;
-    qy = (m[5] + m[7]) * t;
-  }
-  double n = sqrt(qx * qx + qy * qy + qz * qz);
-  if (n != 0.0) {
-    double angle = 2.0 * atan2(n, fabs(qw));
-    double s = angle / (qw < 0.0 ? -n : n);
-    out[0] = qx * s;
-    out[1] = qy * s;
-    out[2] = qz * s;
-  } else {
-    out[0] = out[1] = out[2] = 0.0;
-  }
+  const double tr = m[0] + m[4] + m[8];
+  const bool b0 = tr > 0.0;
+  const bool b1 = !b0 && (m[0] >= m[4]) && (m[0] >= m[8]);  // i = 0
+  const bool b2 = !b0 && !b1 && (m[4] >= m[8]);             // i = 1 (else i = 2)
+  const double d = 1.0 + (b0 ? tr : (b1 ? (m[0] - m[4] - m[8]) : (b2 ? (m[4] - m[8] - m[0]) : (m[8] - m[0] - m[4]))));
+  const double r = rsqrt_nr(d);
+  const double big = 0.5 * (d * r);  // the entry on the pivot: sqrt(d) / 2
+  const double h = 0.5 * r;          // 0.5 / sqrt(d)
+  const double a = (m[7] - m[5]) * h, b = (m[2] - m[6]) * h, c = (m[3] - m[1]) * h;        // antisymmetric parts
+  const double sxy = (m[3] + m[1]) * h, sxz = (m[6] + m[2]) * h, syz = (m[7] + m[5]) * h;  // symmetric parts
+  const double qw = b0 ? big : (b1 ? a : (b2 ? b : c));
+  const double qx = b0 ? a : (b1 ? big : (b2 ? sxy : sxz));
+  const double qy = b0 ? b : (b1 ? sxy : (b2 ? big : syz));
+  const double qz = b0 ? c : (b1 ? sxz : (b2 ? syz : big));
+  // quaternion -> angle-axis: n = |q_v|, angle = 2 atan2(n, |w|), axis = q_v / (w < 0 ? -n : n); n = 0: angle 0
+  const double n2 = qx * qx + qy * qy + qz * qz;
+  const double rn = rsqrt_nr(n2);  // (n2 = 0: not a number, selected away below)
+  const double angle = 2.0 * atan2(n2 * rn, fabs(qw));
+  const double s = (n2 != 0.0) ? (qw < 0.0 ? -angle : angle) * rn : 0.0;
+  out[0] = qx * s;
+  out[1] = qy * s;
+  out[2] = qz * s;
 }
 
 // Per-robot quantities every formulation needs: r_i = Rwb p_i (BC.cpp:244-248)
@@ -576,27 +563,47 @@ QC_DEV void track_swing(CParams& P, double phase, const double (&p0)[3], const d
   }
 }
 
-// K0 + K2 + K3 of SURVEY.md 2.2: gather, PD wrench law, SRB dynamics rhs.
+// K0 + K2 + K3 of SURVEY.md 2.2: gather, PD wrench law, SRB dynamics rhs - in two steps, so that a caller can issue
+// EVERYTHING it reads from memory back to back before the first dependent instruction (fetch_state), and compute
+// afterwards (wrench_from_state).  One dependent memory round trip costs 0.7-1 us here and a wave's fill used to chain
+// six to eight of them (profiles/r03_timeline.log: 2.5 us from kernel entry to "inputs landed" for a lone wave).
+struct RawState {
+  double R[9], Rd[9], x[3], xd[3], xdot[3], xdotd[3], w[3], wd[3];
+};
+// `fp`: the FPL feet from foot0 on (body-frame positions, or joint angles when KIN)
+template <int FPL, bool KIN>
+QC_DEV void fetch_state(const BatchIn& in, long idx, int foot0, RawState& S, double (&fp)[3 * FPL]) {
+  load9(in.Rwb, idx, S.R);
+  load9(in.Rwb_d, idx, S.Rd);
+  load3(in.x, idx, S.x);
+  load3(in.x_d, idx, S.xd);
+  load3(in.xdot, idx, S.xdot);
+  load3(in.xdot_d, idx, S.xdotd);
+  load3(in.w, idx, S.w);
+  load3(in.w_d, idx, S.wd);
+  const double* q = (KIN ? in.joint_q : in.feet) + 12 * idx + 3 * foot0;
+#pragma unroll
+  for (int k = 0; k < 3 * FPL; k++) fp[k] = q[k];
+}
 // `foot0` = first foot owned by this lane; KIN: foot positions from joint_q by
 // forward kinematics instead of the `feet` array.  Returns 0.0 iff every input was finite.
 template <int FPL, bool KIN>
-QC_DEV double build_wrench(CParams& P, const BatchIn& in, long idx, int foot0, Wrench<FPL>& W) {
-  double R[9], Rd[9], x[3], xd[3], xdot[3], xdotd[3], w[3], wd[3];
-  load9(in.Rwb, idx, R);
-  load9(in.Rwb_d, idx, Rd);
-  load3(in.x, idx, x);
-  load3(in.x_d, idx, xd);
-  load3(in.xdot, idx, xdot);
-  load3(in.xdot_d, idx, xdotd);
-  load3(in.w, idx, w);
-  load3(in.w_d, idx, wd);
-  const double* fp = (KIN ? in.joint_q : in.feet) + 12 * idx + 3 * foot0;
+QC_DEV double wrench_from_state(CParams& P, const RawState& S, const double (&fp)[3 * FPL], int foot0, Wrench<FPL>& W) {
+  const double (&R)[9] = S.R;
+  const double (&Rd)[9] = S.Rd;
+  const double (&x)[3] = S.x;
+  const double (&xd)[3] = S.xd;
+  const double (&xdot)[3] = S.xdot;
+  const double (&xdotd)[3] = S.xdotd;
+  const double (&w)[3] = S.w;
+  const double (&wd)[3] = S.wd;
 #pragma unroll
   for (int i = 0; i < FPL; i++) {
     double p0 = fp[3 * i], p1 = fp[3 * i + 1], p2 = fp[3 * i + 2];
     if (KIN) {  // commander_node.cpp:383-384: foot_actual_map = kinematics.forwardKinematics(joint_states_map)
       double pb[3];
-      leg_fk(P, foot0 + i, leg_trig(fp + 3 * i), pb);
+      const double qa[3] = {p0, p1, p2};
+      leg_fk(P, foot0 + i, leg_trig(qa), pb);
       p0 = pb[0]; p1 = pb[1]; p2 = pb[2];
     }
 #pragma unroll
@@ -657,6 +664,13 @@ QC_DEV double build_wrench(CParams& P, const BatchIn& in, long idx, int foot0, W
 #pragma unroll
   for (int k = 0; k < 9; k++) fin = __builtin_fma(R[k], 0.0, fin);
   return fin;
+}
+template <int FPL, bool KIN>
+QC_DEV double build_wrench(CParams& P, const BatchIn& in, long idx, int foot0, Wrench<FPL>& W) {
+  RawState S;
+  double fp[3 * FPL];
+  fetch_state<FPL, KIN>(in, idx, foot0, S, fp);
+  return wrench_from_state<FPL, KIN>(P, S, fp, foot0, W);
 }
 
 // ------------------------------------------------------------ active-set state

@@ -31,6 +31,34 @@ def reduce_counters(dist, wall_s, solved, robots, device=None):
     return float(t.item()), int(c[0].item()), int(c[1].item())
 
 
+def reduce_rank_stats(dist, value, device=None, reps=20):
+    """(min, max) of a per-rank scalar (e.g. each rank's average kernel time) over the group, plus the measured time
+    of one such tiny all-reduce (seconds, mean of `reps` after a warm-up) - the only collective the timed region's
+    bracket uses, reported so that its cost can be seen next to the kernel time."""
+    if dist is None:
+        return float(value), float(value), 0.0
+    import time
+
+    import torch
+
+    kw = {} if device is None else {"device": device}
+    lo = torch.tensor([float(value)], dtype=torch.float64, **kw)
+    hi = lo.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    t = torch.zeros(1, dtype=torch.float64, **kw)
+    on_gpu = device is not None and str(device).startswith("cuda")
+    if on_gpu:
+        torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if on_gpu:
+        torch.cuda.synchronize()
+    return float(lo.item()), float(hi.item()), (time.perf_counter() - t0) / reps
+
+
 def gather_results(dist, grf_shard):
     """Optional result collection: all-gather of the per-rank [n_r, 12] GRF blocks, outside the timed
     hot path.  Returns (gathered tensor [sum n_r, 12] in rank order, seconds).  Shards may be uneven (shard_bounds

@@ -1,4 +1,4 @@
-"""One-off fuzz (not collected by pytest): GPU vs C oracle over many random constructor arguments and workloads,
+"""Fuzz campaign (run() is what tests/test_gpu_fuzz.py calls with a time budget; as a script it runs the long version): GPU vs C oracle over many random constructor arguments and workloads,
 including warm-started second ticks.  usage: python tests/stress_fuzz.py [trials=150] [robots=2048]"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
@@ -7,50 +7,58 @@ import quadruped_control_amd as q
 from quadruped_control_amd import workloads as W
 from oracle import c_oracle as O
 
-trials = int(sys.argv[1]) if len(sys.argv) > 1 else 150
-n = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
-rng = np.random.default_rng(77)
-worst = 0.0; bad = 0; t0 = time.time(); forms = {}
-for trial in range(trials):
-    P = q.cheetah_params(float(rng.choice([0.05, 0.2, 0.6, 1.0, 1.5])) if trial % 5 else float(rng.uniform(0.05, 2.0)))
-    P["fzmin"] = float(rng.choice([0.0, 1.0, 10.0, 40.0]))
-    P["fzmax"] = P["fzmin"] if trial % 17 == 3 else float(P["fzmin"] + 10.0 ** rng.uniform(0.5, 2.5))
-    P["mass"] = float(rng.uniform(2.0, 50.0))
-    P["Ib"] = np.diag(rng.uniform(0.005, 0.5, 3))
-    P["S"] = np.diag(10.0 ** rng.uniform(-1, 2, 6))
-    P["W"] = np.eye(12) * float(10.0 ** rng.uniform(-7, -2))
-    P["kp_p"] = rng.uniform(10, 500, 3); P["kd_p"] = rng.uniform(1, 100, 3)
-    P["kp_w"] = rng.uniform(50, 8000, 3); P["kd_w"] = rng.uniform(5, 800, 3)
-    P["kff"] = rng.uniform(0.0, 0.5, 6)
-    k = trial % 6
-    if k == 1: P["W"] = np.diag(10.0 ** rng.uniform(-6, -3, 12))
-    if k == 2:
-        A = rng.normal(size=(6, 6)); P["S"] = P["S"] + 0.2 * A @ A.T
-    if k == 3:
-        A = rng.normal(size=(12, 12)); P["W"] = P["W"] + 1e-5 * A @ A.T
-    seed = int(rng.integers(1, 2**31))
-    if trial % 2:
-        b0, b1 = W.config4(n, seed=seed)
-    else:
-        b0 = W.config3(n, seed=seed); b1 = None
-    ctl = q.BalanceController.from_params(P)
-    forms[ctl.kernel_name] = forms.get(ctl.kernel_name, 0) + 1
-    o = ctl.control_batch_host(b0, want_active_set=True)
-    ref, st, _ = O.control_batch(P, b0, threads=16)
-    for tag, oo, rr, ss in (("cold", o, ref, st),):
-        okm = (oo["status"] == 0) & (ss == 0)
-        scale = np.maximum(1.0, np.abs(rr).max(axis=1, keepdims=True))
-        err = float(np.max((np.abs(oo["grf_body"] - rr) / scale)[okm])) if okm.any() else 0.0
-        mism = int(((oo["status"] == 0) != (ss == 0)).sum())
-        worst = max(worst, err); bad += mism
-        if err > 1e-6 or mism: print("trial", trial, tag, ctl.kernel_name, "err %.2e status mismatches %d" % (err, mism), {k: (v if np.isscalar(v) else "...") for k, v in P.items() if k in ("mu", "fzmin", "fzmax", "mass")})
-    if b1 is not None:
-        o1 = ctl.control_batch_host(b1, warm=o["active_set"], want_iterations=True)
-        r1, s1, _ = O.control_batch(P, b1, threads=16)
-        okm = (o1["status"] == 0) & (s1 == 0)
-        scale = np.maximum(1.0, np.abs(r1).max(axis=1, keepdims=True))
-        err = float(np.max((np.abs(o1["grf_body"] - r1) / scale)[okm])) if okm.any() else 0.0
-        mism = int(((o1["status"] == 0) != (s1 == 0)).sum())
-        worst = max(worst, err); bad += mism
-        if err > 1e-6 or mism: print("trial", trial, "warm", ctl.kernel_name, "err %.2e status mismatches %d max iters %d" % (err, mism, o1["iterations"].max()))
-print("%d trials x %d robots in %.0f s: worst rel err %.2e, status mismatches %d, kernel forms %s" % (trials, n, time.time() - t0, worst, bad, forms))
+
+
+def run(trials=150, n=2048, budget_s=None, min_trials=6):
+    """Returns (worst relative error over solved robots, status mismatches, trials done); stops early once budget_s is spent."""
+    rng = np.random.default_rng(77)
+    worst = 0.0; bad = 0; t0 = time.time(); forms = {}
+    for trial in range(trials):
+        if budget_s is not None and trial >= min_trials and time.time() - t0 > budget_s: trial -= 1; break
+        P = q.cheetah_params(float(rng.choice([0.05, 0.2, 0.6, 1.0, 1.5])) if trial % 5 else float(rng.uniform(0.05, 2.0)))
+        P["fzmin"] = float(rng.choice([0.0, 1.0, 10.0, 40.0]))
+        P["fzmax"] = P["fzmin"] if trial % 17 == 3 else float(P["fzmin"] + 10.0 ** rng.uniform(0.5, 2.5))
+        P["mass"] = float(rng.uniform(2.0, 50.0))
+        P["Ib"] = np.diag(rng.uniform(0.005, 0.5, 3))
+        P["S"] = np.diag(10.0 ** rng.uniform(-1, 2, 6))
+        P["W"] = np.eye(12) * float(10.0 ** rng.uniform(-7, -2))
+        P["kp_p"] = rng.uniform(10, 500, 3); P["kd_p"] = rng.uniform(1, 100, 3)
+        P["kp_w"] = rng.uniform(50, 8000, 3); P["kd_w"] = rng.uniform(5, 800, 3)
+        P["kff"] = rng.uniform(0.0, 0.5, 6)
+        k = trial % 6
+        if k == 1: P["W"] = np.diag(10.0 ** rng.uniform(-6, -3, 12))
+        if k == 2:
+            A = rng.normal(size=(6, 6)); P["S"] = P["S"] + 0.2 * A @ A.T
+        if k == 3:
+            A = rng.normal(size=(12, 12)); P["W"] = P["W"] + 1e-5 * A @ A.T
+        seed = int(rng.integers(1, 2**31))
+        if trial % 2:
+            b0, b1 = W.config4(n, seed=seed)
+        else:
+            b0 = W.config3(n, seed=seed); b1 = None
+        ctl = q.BalanceController.from_params(P)
+        forms[ctl.kernel_name] = forms.get(ctl.kernel_name, 0) + 1
+        o = ctl.control_batch_host(b0, want_active_set=True)
+        ref, st, _ = O.control_batch(P, b0, threads=16)
+        for tag, oo, rr, ss in (("cold", o, ref, st),):
+            okm = (oo["status"] == 0) & (ss == 0)
+            scale = np.maximum(1.0, np.abs(rr).max(axis=1, keepdims=True))
+            err = float(np.max((np.abs(oo["grf_body"] - rr) / scale)[okm])) if okm.any() else 0.0
+            mism = int(((oo["status"] == 0) != (ss == 0)).sum())
+            worst = max(worst, err); bad += mism
+            if err > 1e-6 or mism: print("trial", trial, tag, ctl.kernel_name, "err %.2e status mismatches %d" % (err, mism), {k: (v if np.isscalar(v) else "...") for k, v in P.items() if k in ("mu", "fzmin", "fzmax", "mass")})
+        if b1 is not None:
+            o1 = ctl.control_batch_host(b1, warm=o["active_set"], want_iterations=True)
+            r1, s1, _ = O.control_batch(P, b1, threads=16)
+            okm = (o1["status"] == 0) & (s1 == 0)
+            scale = np.maximum(1.0, np.abs(r1).max(axis=1, keepdims=True))
+            err = float(np.max((np.abs(o1["grf_body"] - r1) / scale)[okm])) if okm.any() else 0.0
+            mism = int(((o1["status"] == 0) != (s1 == 0)).sum())
+            worst = max(worst, err); bad += mism
+            if err > 1e-6 or mism: print("trial", trial, "warm", ctl.kernel_name, "err %.2e status mismatches %d max iters %d" % (err, mism, o1["iterations"].max()))
+    print("%d trials x %d robots in %.0f s: worst rel err %.2e, status mismatches %d, kernel forms %s" % (trial + 1, n, time.time() - t0, worst, bad, forms))
+    return worst, bad, trial + 1
+
+
+if __name__ == "__main__":
+    run(int(sys.argv[1]) if len(sys.argv) > 1 else 150, int(sys.argv[2]) if len(sys.argv) > 2 else 2048)

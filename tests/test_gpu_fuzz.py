@@ -1,0 +1,24 @@
+"""-m gpu: the fuzz campaigns of tests/stress_fuzz*.py under pytest with a fixed time budget, so that
+the driver runs them: random constructor arguments (mu 0.05-2, w 1e-7-1e-2, fzmin = fzmax, full S, dense W, per-axis W)
+with cold and warm-started ticks, and wild robot states (rotations up to pi, arbitrary contact patterns, large
+velocities) - GPU against the C oracle.  Fixed seeds: the trials are a deterministic sequence, the budget only decides
+how far down the sequence a run gets (the long versions are `python tests/stress_fuzz.py [trials] [robots]`).
+Bars: no status mismatch; forces within north_star's 1e-4 relative (the campaigns' known worst is 2.9e-6, reached by
+parameter sets with w <= 2e-7 where the 6x6 form's conditioning shows - DESIGN.md section 5)."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_parameter_fuzz_30s(built):
+    from tests import stress_fuzz
+
+    worst, mismatches, done = stress_fuzz.run(trials=150, n=2048, budget_s=30.0)
+    assert done >= 6 and mismatches == 0 and worst < 1e-4, (worst, mismatches, done)
+
+
+def test_state_fuzz_30s(built):
+    from tests import stress_fuzz_states
+
+    worst, mismatches, done = stress_fuzz_states.run(batches=40, n=4096, budget_s=30.0)
+    assert done >= 4 and mismatches == 0 and worst < 1e-6, (worst, mismatches, done)

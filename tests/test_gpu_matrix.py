@@ -17,14 +17,18 @@ RTOL = 1e-6  # of max|GRF| per robot; north_star's bar is 1e-4
 FORMS = {"uniform": {}, "general": {"force_general": 1}, "dense": {"force_dense": 1}}
 FORM_ID = {"uniform": 0, "general": 1, "dense": 2}
 # (form, lanes per robot, mode) -> (tuning, robots): every branch of kernel_for()
+import os
+
+# The persistent-wave (mode 0) kernels of the 6x6 forms exist in development builds only (-DQC_PERSISTENT_6X6=1, which no
+# default handle can launch since round 2): QC_TEST_PERSISTENT_6X6=1 adds their rows when such a build is under test.
+PERSISTENT_6X6 = os.environ.get("QC_TEST_PERSISTENT_6X6") == "1"
 CASES = []
 for form in ("uniform", "general"):
-    CASES += [(form, 1, 0, dict(group=1, chunk=256), 8192),
-              (form, 1, 1, dict(group=1, one_fill=1), 8200),  # ragged: the last wave holds 8 robots
-              (form, 2, 0, dict(group=2, chunk=256), 8192),
+    CASES += [(form, 1, 1, dict(group=1, one_fill=1), 8200),  # ragged: the last wave holds 8 robots
               (form, 2, 1, dict(group=2, one_fill=1), 8200),  # ragged: the last wave holds 8 robots
-              (form, 4, 0, dict(group=4, chunk=128), 8192),
               (form, 4, 1, dict(group=4, one_fill=1, race=0), 20480 if form == "uniform" else 8192)]
+    if PERSISTENT_6X6:
+        CASES += [(form, 1, 0, dict(group=1, chunk=256), 8192), (form, 2, 0, dict(group=2, chunk=256), 8192), (form, 4, 0, dict(group=4, chunk=128), 8192)]
 CASES += [("uniform", 4, 2, dict(group=4, one_fill=1, race=0), 8192),
           ("dense", 1, 0, dict(group=1, chunk=256), 8192),
           ("dense", 1, 1, dict(group=1, one_fill=1), 8192),
@@ -118,7 +122,9 @@ def test_kernel_instantiation_vs_oracle(q, form, G, mode, tune, n, start):
         assert _relerr(again["grf_body"].cpu().numpy(), ref) < RTOL
 
 
-KIN_CASES = [c for c in CASES if not (c[0] != "dense" and c[1] == 1 and c[2] == 0)]  # every one-fill branch, every G > 1 branch, both dense widths + [c for c in CASES if c[0] == "uniform" and c[1] == 1]
+# every one-fill branch, every G > 1 branch, both dense widths (the one-lane persistent 6x6 kernels with joint_q spill
+# 532 B per lane and are never planned: kin batches always run as one-fill workgroups)
+KIN_CASES = [c for c in CASES if not (c[0] != "dense" and c[1] == 1 and c[2] == 0)]
 
 
 @pytest.mark.parametrize("form,G,mode,tune,n", KIN_CASES, ids=[f"kin-{f}-G{g}-mode{m}" for f, g, m, _, _ in KIN_CASES])

@@ -347,6 +347,10 @@ def test_graph_capture_replay(q):
     ctl = q.BalanceController.from_params(P)
     d = q.to_device(W.config2(4096))
     launch, out = ctl.plan_batch(d)  # plans only: nothing has been launched yet
+    torch.cuda.synchronize()
+    assert int((out["status"] != -1).sum()) == 0 and float(out["grf_body"].abs().max()) == 0.0  # defined, "not computed yet"
+    with pytest.raises(ValueError, match="iterations"):  # asked for, but the supplied `out` cannot hold it
+        ctl.plan_batch(d, out={"grf_body": out["grf_body"], "status": out["status"]}, want_iterations=True)
     launch()
     torch.cuda.synchronize()
     ref = out["grf_body"].clone()

@@ -23,8 +23,13 @@ for p in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_lds"):
     if not os.path.exists(f):
         continue
     acc = collections.defaultdict(list)
-    for r in csv.DictReader(open(f)):
-        if K in r["Kernel_Name"]:
+    rows = [r for r in csv.DictReader(open(f)) if K in r["Kernel_Name"]]
+    # only the launches of the timed workload: the modal grid (config 4's run also holds the one big tick-0 launch
+    # that produces the warm-start words, and the sweep-free bench still launches a few other sizes)
+    grids = collections.Counter(r["Grid_Size"] for r in rows)
+    modal = grids.most_common(1)[0][0] if grids else None
+    for r in rows:
+        if r["Grid_Size"] == modal:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
             res = {k: r[k] for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Grid_Size", "Workgroup_Size")}
     for k, v in acc.items():
@@ -45,6 +50,18 @@ if os.path.exists(bl) and os.path.getsize(bl):
     out["algorithmic_bytes_per_launch"] = rl["bytes_per_launch"]
     if "traffic" in out:
         out["traffic"]["ratio_to_algorithmic"] = out["traffic"]["hbm_bytes_per_launch"] / rl["bytes_per_launch"]
+# The bound that actually binds the solve: FP64 VALU issue.  One wave-instruction occupies a SIMD's FP64 pipe for 4 cycles
+# (64 lanes over 16-wide pipes), so issue_frac = SQ_INSTS_VALU x 4 / (SIMDs x kernel cycles); MI355X: 256 CUs x 4 SIMDs, 2.4 GHz.
+if "SQ_INSTS_VALU" in counters and krows and "bench_line" in out:
+    main = max(krows, key=lambda r: float(r["TotalDurationNs"]))
+    robots = out["bench_line"]["config"]["robots_per_gpu"]
+    kernel_ns = float(out["bench_line"]["roofline"]["avg_kernel_us"]) * 1e3  # HIP-event average of the timed launches
+    cycles = kernel_ns * 2.4
+    out["valu"] = {"insts_valu_per_launch": counters["SQ_INSTS_VALU"], "insts_valu_per_robot": counters["SQ_INSTS_VALU"] * 64.0 / robots / 64.0 * 64.0 / 64.0,
+                   "wave_insts_per_wave": counters["SQ_INSTS_VALU"] / counters["SQ_WAVES"] if counters.get("SQ_WAVES") else None,
+                   "issue_frac": counters["SQ_INSTS_VALU"] * 4.0 / (1024.0 * cycles), "simds": 1024, "clock_ghz": 2.4, "cycles_per_wave_inst": 4,
+                   "kernel_ns": kernel_ns, "rocprof_avg_ns": float(main["AverageNs"])}
+    out["valu"]["insts_valu_per_robot"] = counters["SQ_INSTS_VALU"] / robots  # wave-instructions per robot (a wave-instruction serves up to 64 lanes)
 json.dump(out, open(os.path.join(dst, tag + ".json"), "w"), indent=1)
 with open(os.path.join(dst, tag + ".md"), "w") as f:
     f.write(f"# rocprofv3 summary `{tag}`\n\n")
@@ -61,6 +78,12 @@ with open(os.path.join(dst, tag + ".md"), "w") as f:
         f.write(f"* fetch (corrected): {t['fetch_bytes_corrected_x2']:.0f} B, write: {t['write_bytes']:.0f} B, total {t['hbm_bytes_per_launch']:.0f} B\n")
         if "ratio_to_algorithmic" in t:
             f.write(f"* algorithmic bytes per launch: {out['algorithmic_bytes_per_launch']} -> measured/algorithmic = {t['ratio_to_algorithmic']:.2f}\n")
+    if "valu" in out:
+        v = out["valu"]
+        f.write("\n## FP64 VALU issue (the bound that binds the solve)\n\n")
+        f.write(f"* {v['insts_valu_per_launch']:.0f} VALU wave-instructions per launch = {v['insts_valu_per_robot']:.2f} per robot"
+                + (f" = {v['wave_insts_per_wave']:.0f} per wave" if v["wave_insts_per_wave"] else "") + "\n")
+        f.write(f"* issue fraction = insts x 4 cycles / (1024 SIMDs x {v['kernel_ns']:.0f} ns x 2.4 GHz) = **{v['issue_frac']:.3f}**\n")
     if "bench_line" in out:
         f.write("\n## bench line of the profiled run\n\n```\n" + json.dumps(out["bench_line"]) + "\n```\n")
 print(open(os.path.join(dst, tag + ".md")).read())

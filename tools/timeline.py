@@ -1,0 +1,70 @@
+"""Development tool (round 3): timeline of one launch, from tools/_build/libqc_timeline.so (tools/timeline.hip) - per
+workgroup: entry, inputs landed, solve finished, end (100 MHz s_memrealtime) and the hardware slot.  Prints, per
+microsecond of the launch: workgroups started, workgroups in their load / solve / flush phase, input bytes that landed
+(as TB/s), and the phase-length statistics.  usage: python tools/timeline.py [cfg4|cfg5s|cfg3|2M] [rotate] [key=value ...]"""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+import numpy as np, torch
+from quadruped_control_amd import _lib
+_lib.LIB_PATH = os.environ.get("QC_TL_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "libqc_timeline.so")
+import quadruped_control_amd as q
+from quadruped_control_amd import workloads as W
+from quadruped_control_amd import workloads_device as WD
+
+what = sys.argv[1] if len(sys.argv) > 1 else "cfg4"
+rotate = "rotate" in sys.argv[2:]
+sys.argv = [a for a in sys.argv if a not in ("rotate",)]
+tune = {a.split("=")[0]: float(a.split("=")[1]) for a in sys.argv[2:] if "=" in a}
+brief = "brief" in sys.argv[2:]
+kind, n = {"cfg4": ("warm", 262144), "cfg5s": ("cold", 262144), "cfg3": ("cold", 65536), "2M": ("cold", 2097152), "1M": ("cold", 1048576),
+           "16k": ("cold", 16384), "4k": ("cold", 4096), "32k": ("cold", 32768)}[what]
+P = q.cheetah_params(0.6)
+ctl = q.BalanceController.from_params(P).set_tuning(**tune)
+nsets = ((512 << 20) // (488 * n) + 1) if rotate else 1
+ls = []
+keep = []
+for j in range(nsets):
+    if kind == "warm":
+        t0, t1 = W.config4(n, seed=W.SEEDS[4] + 0x100 * j)
+        w = q.BalanceController.from_params(P).control_batch(q.to_device(t0), want_active_set=True)["active_set"]
+        b = q.to_device(t1)
+    else:
+        b, w = WD.config3(n, seed=W.SEEDS[5] + 0x100 * j, device=0), None
+    l, o = ctl.plan_batch(b, warm=w, want_active_set=w is not None)
+    ls.append(l); keep.append((b, w, o))
+for i in range(3 * len(ls) + 1):
+    ls[i % len(ls)]()
+torch.cuda.synchronize()
+info = ctl.query_launch(n, warm=kind == "warm")
+blocks = info["blocks"]
+buf = (C.c_ulonglong * (5 * blocks))()
+assert ctl._lib.qc_timeline_read(buf, blocks) == 0
+t = np.array(list(buf), dtype=np.uint64).reshape(blocks, 5)
+hw = t[:, 4]
+ts = t[:, :4].astype(np.int64)
+t00 = ts[:, 0].min()
+us = (ts - t00) / 100.0  # 100 MHz -> us
+span = us[:, 3].max()
+per_wg = info["chunk"] * (392 + (4 if kind == "warm" else 0))
+print("%s n=%d %s: %d workgroups (G=%d mode %d), launch span %.1f us (first entry -> last end)" %
+      (what, n, "rotating sets (cold cache)" if rotate else "one resident set", blocks, info["lanes_per_robot"], info["mode"], span))
+ph = np.stack([us[:, 1] - us[:, 0], us[:, 2] - us[:, 1], us[:, 3] - us[:, 2], us[:, 3] - us[:, 0]], 1)
+for k, nm in enumerate(("entry -> inputs landed", "inputs landed -> solve done", "flush (transform + stores acked)", "whole workgroup")):
+    v = ph[:, k]
+    print("  %-34s mean %6.2f  p10 %6.2f  p50 %6.2f  p90 %6.2f  max %6.2f us" % (nm, v.mean(), *np.percentile(v, [10, 50, 90]), v.max()))
+slots = len(np.unique(hw))
+print("  distinct hardware wave slots used: %d; workgroups per slot: mean %.2f max %d" % (slots, blocks / slots, np.unique(hw, return_counts=True)[1].max()))
+if brief:
+    sys.exit(0)
+edges = np.arange(0, np.ceil(span) + 1)
+print("  t[us]  started  in-load  in-solve  in-flush  resident  inputs landed [TB/s]  results stored [TB/s]")
+for a in edges[:-1]:
+    b_ = a + 1
+    started = int(((us[:, 0] >= a) & (us[:, 0] < b_)).sum())
+    mid = a + 0.5
+    inload = int(((us[:, 0] <= mid) & (us[:, 1] > mid)).sum())
+    insolve = int(((us[:, 1] <= mid) & (us[:, 2] > mid)).sum())
+    inflush = int(((us[:, 2] <= mid) & (us[:, 3] > mid)).sum())
+    landed = ((us[:, 1] >= a) & (us[:, 1] < b_)).sum() * per_wg / 1e-6 / 1e12
+    stored = ((us[:, 3] >= a) & (us[:, 3] < b_)).sum() * info["chunk"] * 100 / 1e-6 / 1e12
+    print("  %5.0f  %7d  %7d  %8d  %8d  %8d  %20.2f  %21.2f" % (a, started, inload, insolve, inflush, inload + insolve + inflush, landed, stored))
