@@ -29,6 +29,10 @@ def _worker(rank, world, port, n, q):
     batch = W.config5(n=hi - lo, start=lo)
     grf, status, _ = c_oracle.control_batch(R.cheetah_params(0.6), batch)
     wall, solved, robots = reduce_counters(dist, 1.0 + rank, int((status == 0).sum()), hi - lo)
+    from quadruped_control_amd.sharding import reduce_rank_stats
+
+    k_min, k_max, allreduce_s = reduce_rank_stats(dist, 10.0 + rank, reps=5)  # per-rank kernel time -> min / max over the group
+    assert (k_min, k_max) == (10.0, 9.0 + world) and allreduce_s > 0.0
     gathered = [None] * world
     dist.all_gather_object(gathered, (lo, hi, grf))
     dist.barrier()
