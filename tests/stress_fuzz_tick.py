@@ -1,4 +1,4 @@
-"""One-off fuzz (not collected by pytest): the widened tick (joint_q -> FK -> control -> J^T, swing legs IK + J^-1 + PD)
+"""Fuzz campaign (run() is what tests/test_gpu_fuzz.py calls with a time budget; as a script it runs the long version): the widened tick (joint_q -> FK -> control -> J^T, swing legs IK + J^-1 + PD)
 with random kinematic models, wild joint angles (incl. stretched / folded legs) and swing references far from the
 feet, GPU vs C oracle.  usage: python tests/stress_fuzz_tick.py [batches=30] [robots=4096]"""
 import os, sys, time
@@ -8,40 +8,48 @@ import quadruped_control_amd as q
 from quadruped_control_amd import workloads as W
 from oracle import c_oracle as O
 
-batches = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
-rng = np.random.default_rng(999)
-worst = 0.0; worst_f = 0.0; mism = 0; t0 = time.time(); flips = 0
-for bi in range(batches):
-    P = q.cheetah_params(float(rng.choice([0.4, 0.6, 0.8])))
-    kin = O.default_kinematics()
-    hip = np.array(kin.hip[:]) * rng.uniform(0.7, 1.3, 12)
-    links = np.array(kin.links[:]) * rng.uniform(0.7, 1.4, 12)
-    tmax = float(rng.choice([5.0, 20.0, 60.0]))
-    kp = rng.uniform(5, 80, 3); kd = rng.uniform(0.1, 3, 3); kff = rng.uniform(0, 0.5, 3)
-    kin.hip[:] = list(hip); kin.links[:] = list(links); kin.tau_min = -tmax; kin.tau_max = tmax
-    kin.jc_kp[:] = list(kp); kin.jc_kd[:] = list(kd); kin.jc_kff[:] = list(kff)
-    ctl = q.BalanceController.from_params(P)
-    ctl.set_kinematics(hip=hip, links=links, tau_min=-tmax, tau_max=tmax, jc_kp=kp, jc_kd=kd, jc_kff=kff)
-    b = W.with_swing_references(W.with_joint_angles(W.config3(n, seed=int(rng.integers(1, 2**31)))))
-    spread = float(rng.choice([0.3, 1.0, 3.0]))
-    b["joint_q"] = np.ascontiguousarray(np.tile(W.NOMINAL_JOINTS, 4)[None] + rng.uniform(-spread, spread, (n, 12)))
-    b["joint_qdot"] = np.ascontiguousarray(rng.uniform(-10, 10, (n, 12)))
-    b["swing_pos"] = np.ascontiguousarray(b["swing_pos"] + rng.uniform(-1, 1, (n, 12)) * float(rng.choice([0.01, 0.1, 0.6])))
-    b["swing_vel"] = np.ascontiguousarray(rng.uniform(-3, 3, (n, 12)))
-    o = ctl.control_batch_host(b, want_torques=True)
-    ref = O.tick_swing_batch(P, b, kin=kin, threads=16)
-    mism += int((o["status"] != ref["status"]).sum())
-    okm = (o["status"] == 0) & (ref["status"] == 0)
-    scale = np.maximum(1.0, np.abs(ref["grf_body"]).max(axis=1, keepdims=True))
-    ef = float((np.abs(o["grf_body"] - ref["grf_body"]) / scale)[okm].max()) if okm.any() else 0.0
-    d = np.abs(o["joint_tau"] - ref["joint_tau"]) / tmax
-    big = d > 1e-6
-    flips += int(big.sum())
-    worst_f = max(worst_f, ef); worst = max(worst, float(d.max()))
-    if ef > 1e-6 or big.any() or mism:
-        i, j = np.unravel_index(np.argmax(d), d.shape)
-        print("batch %d spread %.1f: grf err %.2e, torque err %.2e of tau_max (robot %d joint %d: gpu %.6f oracle %.6f, stance %s), %d entries > 1e-6, status mismatches %d" %
-              (bi, spread, ef, d.max(), i, j, o["joint_tau"][i, j], ref["joint_tau"][i, j], b["stance"][i], int(big.sum()), mism))
-print("%d batches x %d robots in %.0f s: worst grf err %.2e, worst torque err %.2e of tau_max, entries > 1e-6: %d of %d, status mismatches %d" %
-      (batches, n, time.time() - t0, worst_f, worst, flips, batches * n * 12, mism))
+
+
+def run(batches=30, n=4096, budget_s=None, min_batches=3):
+    """Returns (worst GRF error, worst torque error / tau_max, torque entries off by > 1e-6, status mismatches, batches done)."""
+    rng = np.random.default_rng(999)
+    worst = 0.0; worst_f = 0.0; mism = 0; t0 = time.time(); flips = 0
+    for bi in range(batches):
+        if budget_s is not None and bi >= min_batches and time.time() - t0 > budget_s: bi -= 1; break
+        P = q.cheetah_params(float(rng.choice([0.4, 0.6, 0.8])))
+        kin = O.default_kinematics()
+        hip = np.array(kin.hip[:]) * rng.uniform(0.7, 1.3, 12)
+        links = np.array(kin.links[:]) * rng.uniform(0.7, 1.4, 12)
+        tmax = float(rng.choice([5.0, 20.0, 60.0]))
+        kp = rng.uniform(5, 80, 3); kd = rng.uniform(0.1, 3, 3); kff = rng.uniform(0, 0.5, 3)
+        kin.hip[:] = list(hip); kin.links[:] = list(links); kin.tau_min = -tmax; kin.tau_max = tmax
+        kin.jc_kp[:] = list(kp); kin.jc_kd[:] = list(kd); kin.jc_kff[:] = list(kff)
+        ctl = q.BalanceController.from_params(P)
+        ctl.set_kinematics(hip=hip, links=links, tau_min=-tmax, tau_max=tmax, jc_kp=kp, jc_kd=kd, jc_kff=kff)
+        b = W.with_swing_references(W.with_joint_angles(W.config3(n, seed=int(rng.integers(1, 2**31)))))
+        spread = float(rng.choice([0.3, 1.0, 3.0]))
+        b["joint_q"] = np.ascontiguousarray(np.tile(W.NOMINAL_JOINTS, 4)[None] + rng.uniform(-spread, spread, (n, 12)))
+        b["joint_qdot"] = np.ascontiguousarray(rng.uniform(-10, 10, (n, 12)))
+        b["swing_pos"] = np.ascontiguousarray(b["swing_pos"] + rng.uniform(-1, 1, (n, 12)) * float(rng.choice([0.01, 0.1, 0.6])))
+        b["swing_vel"] = np.ascontiguousarray(rng.uniform(-3, 3, (n, 12)))
+        o = ctl.control_batch_host(b, want_torques=True)
+        ref = O.tick_swing_batch(P, b, kin=kin, threads=16)
+        mism += int((o["status"] != ref["status"]).sum())
+        okm = (o["status"] == 0) & (ref["status"] == 0)
+        scale = np.maximum(1.0, np.abs(ref["grf_body"]).max(axis=1, keepdims=True))
+        ef = float((np.abs(o["grf_body"] - ref["grf_body"]) / scale)[okm].max()) if okm.any() else 0.0
+        d = np.abs(o["joint_tau"] - ref["joint_tau"]) / tmax
+        big = d > 1e-6
+        flips += int(big.sum())
+        worst_f = max(worst_f, ef); worst = max(worst, float(d.max()))
+        if ef > 1e-6 or big.any() or mism:
+            i, j = np.unravel_index(np.argmax(d), d.shape)
+            print("batch %d spread %.1f: grf err %.2e, torque err %.2e of tau_max (robot %d joint %d: gpu %.6f oracle %.6f, stance %s), %d entries > 1e-6, status mismatches %d" %
+                  (bi, spread, ef, d.max(), i, j, o["joint_tau"][i, j], ref["joint_tau"][i, j], b["stance"][i], int(big.sum()), mism))
+    print("%d batches x %d robots in %.0f s: worst grf err %.2e, worst torque err %.2e of tau_max, entries > 1e-6: %d of %d, status mismatches %d" %
+          (bi + 1, n, time.time() - t0, worst_f, worst, flips, (bi + 1) * n * 12, mism))
+    return worst_f, worst, flips, mism, bi + 1
+
+
+if __name__ == "__main__":
+    run(int(sys.argv[1]) if len(sys.argv) > 1 else 30, int(sys.argv[2]) if len(sys.argv) > 2 else 4096)
