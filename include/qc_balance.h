@@ -222,14 +222,18 @@ int qc_query_launch(qc_handle* h, size_t n, int kin, int warm, qc_launch_info* o
 
 /* ABI v4.  Development / test interface: explicit overrides of the launch heuristics and solver constants (the
  * library reads NO environment variables).  Keys: "group" (lanes per robot: 0 = heuristic, 1, 2, 4), "one_fill"
- * (-1 heuristic, 0 persistent waves, 1 one-fill workgroups), "chunk" (robots per wave, 0 = heuristic),
+ * (-1 heuristic, 0 persistent waves, 1 one-fill workgroups; the persistent kernels of the 6x6 forms exist only in
+ * development builds, -DQC_PERSISTENT_6X6=1: elsewhere those forms always run as one-fill workgroups and 0 applies to the
+ * one-lane dense form), "chunk" (robots per wave, 0 = heuristic; beyond one fill only where persistent kernels exist),
  * "wave_slots" (resident workgroups assumed, 0 = occupancy query), "refill_t", "rounds_cold", "rounds_warm",
  * "race" (-1 heuristic; 0 or 1: one strategy per robot; 2, 4: at most that many racing in the 4-lane one-fill kernels),
  * "force_general" / "force_dense" (run the more general formulation on weights that would allow the
  * specialised one; same minimiser), "clamp_steps" (clamp steps a cold-started robot takes before its first ratio test in
  * the one-fill kernels; 0 = the kernel's rule: five on one or two lanes per robot, one on four),
- * "tol_d" (relative multiplier tolerance), "max_iter", "probe_batch_load"
- * (1: skip the solver iterations - load, assemble, store only; every robot then reports QC_MAX_ITER).
+ * "tol_d" (relative multiplier tolerance), "max_iter" (<= 0: back to qc_params.max_iter), "probe_batch_load"
+ * (1: skip the solver iterations - load, assemble, store only; every robot then reports QC_MAX_ITER; 0: back to the
+ * handle's own cap).  "force_general" / "force_dense" / "max_iter" / "probe_batch_load" restore what qc_create was given,
+ * whatever the order of the calls.
  * Calls that change device constants synchronise the device first.  Returns QC_ERR_INVALID for an unknown key. */
 int qc_set_tuning(qc_handle* h, const char* key, double value);
 

@@ -826,3 +826,36 @@ def test_on_device_generation_matches_host(q):
     assert int((o["status"] != 0).sum()) == 0 and (st == 0).all()
     scale = np.maximum(1.0, np.abs(ref).max(axis=1, keepdims=True))
     assert np.max(np.abs(o["grf_body"].cpu().numpy() - ref) / scale) < 1e-6
+
+
+def test_tuning_overrides_restore_what_the_handle_was_created_with(q):
+    """qc_set_tuning's overrides restore the creation-time values - the handle's own iteration cap after the
+    batch-load probe or max_iter <= 0 (not a hard-coded 200), and the weights' own formulation after any order of
+    force_general / force_dense calls (not a form re-derived from the current flags)."""
+    from quadruped_control_amd import workloads as W
+
+    P = q.cheetah_params(0.6)
+    b = W.config3(4096, seed=0x5EED00B7)
+    fresh = q.BalanceController.from_params(P, max_iter=3).control_batch_host(b, want_iterations=True)
+    assert (fresh["status"] == 1).any() and int(fresh["iterations"].max()) == 3
+    ctl = q.BalanceController.from_params(P, max_iter=3)
+    ctl.set_tuning(probe_batch_load=1)
+    probe = ctl.control_batch_host(b)
+    assert (probe["status"] == 1).all() and np.all(probe["grf_body"] == 0.0)  # load -> assemble -> store only
+    ctl.set_tuning(probe_batch_load=0)
+    back = ctl.control_batch_host(b, want_iterations=True)
+    assert np.array_equal(back["status"], fresh["status"]) and np.array_equal(back["iterations"], fresh["iterations"])
+    ctl.set_tuning(max_iter=100).set_tuning(max_iter=0)
+    again = ctl.control_batch_host(b, want_iterations=True)
+    assert np.array_equal(again["status"], fresh["status"]) and np.array_equal(again["iterations"], fresh["iterations"])
+    # formulation: uniform weights stay uniform after a detour through the other forms, in any order
+    ctl = q.BalanceController.from_params(P)
+    assert ctl.query_launch(4096)["form"] == 0
+    ctl.set_tuning(force_dense=1).set_tuning(force_general=0)
+    assert ctl.query_launch(4096)["form"] == 2
+    ctl.set_tuning(force_dense=0)
+    assert ctl.query_launch(4096)["form"] == 0 and ctl.kernel_name == "diagW-6x6-uniform"
+    ctl.set_tuning(force_general=1).set_tuning(force_dense=1).set_tuning(force_general=0)
+    assert ctl.query_launch(4096)["form"] == 2
+    ctl.set_tuning(force_dense=0)
+    assert ctl.query_launch(4096)["form"] == 0
