@@ -205,7 +205,8 @@ int qc_abi_version(void);
 /* ABI v4.  Which kernel instantiation a batch of n robots would run on (kin = joint_q given, warm = warm-start
  * words given): lanes per robot, kernel mode (0 persistent waves with lane refill, 1 one fill per wave, 2 one fill
  * and one wave per SIMD with register-resident constants; batches that leave SIMDs idle even so race 2 or 4 pivoting
- * strategies per robot there, `strategies`), form (0 uniform 6x6, 1 general 6x6, 2 dense 12x12),
+ * strategies per robot there, `strategies`; 3 paired waves - two one-lane waves per workgroup, the last to arrive
+ * finishes both waves' stragglers: 6x6 forms from 524 288 robots on), form (0 uniform 6x6, 1 general 6x6, 2 dense 12x12),
  * robots per wave, grid size, and the workgroups of that kernel the device holds at once (the occupancy query the
  * heuristics use). */
 typedef struct qc_launch_info {
@@ -227,6 +228,8 @@ int qc_query_launch(qc_handle* h, size_t n, int kin, int warm, qc_launch_info* o
  * one-lane dense form), "chunk" (robots per wave, 0 = heuristic; beyond one fill only where persistent kernels exist),
  * "wave_slots" (resident workgroups assumed, 0 = occupancy query), "refill_t", "rounds_cold", "rounds_warm",
  * "race" (-1 heuristic; 0 or 1: one strategy per robot; 2, 4: at most that many racing in the 4-lane one-fill kernels),
+ * "pair" (-1 heuristic, 0 never, 1 whenever one lane per robot on a 6x6 form: the paired-waves kernel, mode 3), "pair_th"
+ * (its hand-over threshold, <= 32), "pair_refill", "pair_solo" (0: pairs in the last round of workgroups too),
  * "force_general" / "force_dense" (run the more general formulation on weights that would allow the
  * specialised one; same minimiser), "clamp_steps" (clamp steps a cold-started robot takes before its first ratio test in
  * the one-fill kernels; 0 = the kernel's rule: five on one or two lanes per robot, one on four),

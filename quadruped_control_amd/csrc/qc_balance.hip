@@ -1034,6 +1034,259 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
 }
 
 
+
+// ----------------------------------------------------------------------------------------------------------------
+// MODE 3, paired waves (round 3): the one-lane kernel of batches that need more than one round of workgroups.
+//
+// A workgroup is TWO waves = 128 consecutive robots.  Each wave fills and takes its clamp steps exactly as the one-fill
+// kernel does (one lane per robot, every load in one batch, Rwb parked in LDS), stores the robots that are finished straight
+// from its registers, and writes the state of those still running - 33 doubles each - to a RECORD list in the
+// workgroup's LDS.  Then it bumps an LDS counter: the wave that arrives FIRST simply ends (its wave slot is free for
+// the next workgroup; nothing ever waits at a barrier after the first microsecond), the one that arrives LAST finishes
+// both waves' stragglers four lanes per robot on the strided MFMA body, sixteen at a time, REFILLING lane groups from
+// the list as robots finish, and races the two drop rules on the last <= 8 (cold batches).
+// Why: in the one-fill kernel every wave finishes its own <= 16 stragglers and stays until the slowest is done - 5.65 tail
+// recalculations per wave on config 5, mostly with a few of the 16 lane groups live.  Two waves' stragglers (~38 after
+// five clamp steps) keep the 16 groups full for most of the walk: 4.8 tail recalculations per wave in the prototype
+// (oracle/prototypes/proto_straggler_queue.py, K = 2) and no one-lane recalculation at 30 % occupancy in between.
+// The same idea through a list in GLOBAL memory shared by K workgroups lost (tools/experiments/straggler_queue.patch: a
+// memory round trip per refill, and a K-waves-long serial chain at the end of the launch); here a refill is a handful
+// of ds_reads and the chain is two waves' worth.  And as ONE persistent wave that alternates fills and list consumption
+// (tools/experiments/straggler_list_persistent.patch) it lost to code generation: a loop around the two heavy phases makes
+// the compiler hoist invariants above bodies that need all 256 registers - scratch, whose first touch costs a wave ~10 us.
+// Measured (profiles/r03_paired_waves.log): -5 % from four rounds of workgroups on (524 288 robots: 164 -> 156 us, 1 M: 300 ->
+// 285, 2 M: 545 -> 515), nothing at two rounds - the early wave's slot idles until a second one is free for the next
+// two-wave workgroup - which is where the planner draws the line.
+constexpr int PAIR_REC = 33;    // doubles per record (odd: the records of the 16 lane groups fall into different banks):
+                                // 0-5 -b, 6 {slot | stance << 8 | face codes << 24 | iters << 48}, 7-18 r, 19-30 f
+constexpr int PAIR_CAP = 32;    // records a wave may leave (hand-over threshold <= PAIR_CAP)
+struct PairLds {
+  double Rrows[128 * 9];                 // Rwb of the workgroup's robots, for the output transform
+  double rec[2 * PAIR_CAP * PAIR_REC];   // the record list; once it is drained, the race stage's re-pack area
+  int count[2], arrived;  // records in the list (paired: count[0]; solo: one list per wave)
+};
+
+template <class Eqp, bool KIN>
+__global__ __launch_bounds__(128, 2) void balance_pair_kernel(const DevParams* __restrict__ Pg, const long n, const BatchIn in,
+                                                              const uint32_t* __restrict__ warm, const BatchOut out, const int th,
+                                                              const int refill, const int race, const unsigned solo_from) {
+  static_assert(Eqp::G == 1 && Eqp::kNegB, "one lane per robot, 6x6 forms");
+  static_assert(8 * REPACK_RS <= PAIR_CAP * PAIR_REC, "the race stage re-packs into the drained list (a solo wave's half of it)");
+  constexpr bool UNIFORM = Eqp::kUniform;
+  using Lane1 = Lane<Eqp, KIN>;
+  using Eqp4 = EqpDiagW<UNIFORM, 4, true>;
+  using Lane4 = Lane<Eqp4, KIN>;
+  using LaneR = Lane<Eqp4, KIN, true>;  // with a per-lane drop rule
+  __shared__ PairLds lds;
+  const int lane = threadIdx.x & 63;
+  const int slot = threadIdx.x;  // 0 ... 127: this robot's place in the workgroup (= its Rwb row)
+  const long base = (long)blockIdx.x * 128;
+  const long robot = base + slot;
+  const bool mine = robot < n;
+  QC_CLK_BEGIN();
+  // SOLO: the workgroups of the launch's LAST round keep their stragglers to themselves - each wave is the consumer of its own
+  // list.  Behind them no workgroup is waiting for a wave slot, so nothing is gained by ending early, and a wave's own list
+  // is the shorter chain at the end of the launch.
+  const bool solo = blockIdx.x >= solo_from;
+  const int wv_id = threadIdx.x >> 6;
+  if (threadIdx.x == 0) { lds.count[0] = 0; lds.count[1] = 0; lds.arrived = 0; }
+  __syncthreads();  // the only barrier: both waves have just started
+  double* const list = lds.rec + (solo ? wv_id * PAIR_CAP * PAIR_REC : 0);
+  int* const list_n = &lds.count[solo ? wv_id : 0];
+  // ---------------------------------------------------------------- producer: one lane per robot
+  {
+    Lane1 L;
+    Eqp eqp(nullptr);
+    L.idx = -1;
+    L.foot0 = 0;
+    L.stance = 0;
+    bool busy = false;
+    if (mine) {
+      const uint32_t sw = in.stance ? *reinterpret_cast<const uint32_t*>(in.stance + 4 * robot) : 0u;
+      const uint32_t wv = warm ? warm[robot] : 0u;
+      RawState S;
+      double fp[12];
+      fetch_state<4, KIN>(in, robot, 0, S, fp);
+      asm volatile("" ::: "memory");  // (every load of the fill is issued above this line)
+      CParams& P = *QC_PARAMS_HERE(Pg);
+      Wrench<4> W;
+      const uint32_t st = assemble_from_state<KIN, 4, false>(P, in, robot, 0, S, fp, sw, W);
+#pragma unroll
+      for (int k = 0; k < 9; k++) lds.Rrows[9 * slot + k] = S.R[k];
+      L.load_direct(W, st, wv, robot, 0);
+      eqp.setup(P, L.Wr, 0);
+      busy = P.max_iter != 0;  // (0: the batch-load probe - load -> assemble -> store only)
+    }
+    QC_CLK(0, 2);
+    const int first_steps = clamp_steps_for<1>(*QC_PARAMS_HERE(Pg), warm);
+#pragma unroll 1
+    for (int k = 0; k < first_steps; k++)
+      if (busy) busy = !L.template iterate<Lane1::FIRST>(*QC_PARAMS_HERE(Pg), eqp);
+    unsigned long long bm = __builtin_amdgcn_ballot_w64(busy);
+    while (__builtin_popcountll(bm) > th) {
+      if (busy) busy = !L.template iterate<Lane1::STEADY>(*QC_PARAMS_HERE(Pg), eqp);
+      bm = __builtin_amdgcn_ballot_w64(busy);
+    }
+    if (mine && !busy) {
+      CParams& P = *QC_PARAMS_HERE(Pg);
+      store_result<KIN, 4>(P, in, out, robot, L.stance, L.status, L.iters, L.word_bits() | 0x80000000u, L.f, 0, lds.Rrows + 9 * slot, 1);
+    }
+    const int nb = __builtin_popcountll(bm);
+    int first = 0;
+    if (nb > 0 && lane == 0) first = __hip_atomic_fetch_add(list_n, nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    first = __builtin_amdgcn_readfirstlane(first);
+    if (busy) {
+      const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0));
+      double* rec = list + (first + rank) * PAIR_REC;
+#pragma unroll
+      for (int k = 0; k < 6; k++) rec[k] = L.Wr.b[k];
+      const unsigned long long fl = (unsigned long long)slot | ((unsigned long long)(L.stance & 0x1FFu) << 8) |
+                                    ((unsigned long long)(L.word_bits() & 0xFFFFFFu) << 24) | ((unsigned long long)(uint32_t)L.iters << 48);
+      rec[6] = __longlong_as_double((long long)fl);
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          rec[7 + 3 * i + k] = L.Wr.r[i][k];
+          rec[19 + 3 * i + k] = L.f[3 * i + k];
+        }
+    }
+  }
+  // ---------------------------------------------------------------- hand-over inside the workgroup: the last wave to arrive consumes
+  int arrived = 1;
+  if (!solo) {
+    if (lane == 0) arrived = __hip_atomic_fetch_add(&lds.arrived, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+    arrived = __builtin_amdgcn_readfirstlane(arrived);
+  }
+  if (arrived == 0) {
+    QC_CLK_END(8);
+    return;
+  }
+  const int T = __hip_atomic_load(list_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  if (T == 0) {
+    QC_CLK_END(8);
+    return;
+  }
+  QC_CLK(7, 8);
+  // ---------------------------------------------------------------- consumer: four lanes per robot, refilled from the list
+  const int g4 = lane & 15, j4 = lane >> 4;
+  Lane4 L4;
+  Eqp4 eqp4(nullptr);
+  int rslot = 0;  // the robot's place in the workgroup (its Rwb row)
+  auto take = [&](int t) {
+    const double* rec = list + t * PAIR_REC;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      L4.Wr.b[k] = rec[k];  // (already -b)
+      asm volatile("" : "+v"(L4.Wr.b[k]));
+    }
+    const unsigned long long fl = (unsigned long long)__double_as_longlong(rec[6]);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      L4.Wr.r[0][k] = rec[7 + 3 * j4 + k];
+      L4.f[k] = rec[19 + 3 * j4 + k];
+    }
+    rslot = (int)(fl & 0xFFu);
+    L4.idx = base + rslot;
+    L4.stance = (uint32_t)((fl >> 8) & 0x1FFu);
+    const uint32_t fw = (uint32_t)(fl >> (24 + 6 * j4));
+    L4.C.sx[0] = dec2(fw); L4.C.sy[0] = dec2(fw >> 2); L4.C.sz[0] = dec2(fw >> 4);
+    L4.iters = (int)(fl >> 48);
+    L4.foot0 = j4;
+    L4.status = QC_MAX_ITER;
+    L4.have_f = true;
+    eqp4.setup(*QC_PARAMS_HERE(Pg), L4.Wr, j4);
+  };
+  auto push4 = [&](const Lane4& X, int rs) {  // this lane's foot of a finished robot, straight to the outputs
+    const uint32_t word = (uint32_t)group_or<4, true>((int)X.word_bits()) | 0x80000000u;
+    CParams& P = *QC_PARAMS_HERE(Pg);
+    store_result<KIN, 1>(P, in, out, X.idx, X.stance, X.status, X.iters, word, X.f, j4, lds.Rrows + 9 * rs, 1);
+  };
+  // groups without a robot shadow ticket 0 (the strided layout keeps every lane in the loop: MFMA sums read all 64)
+  bool busy4 = g4 < T;
+  bool holds = busy4;  // the group holds a robot whose result has not been stored yet
+  take(busy4 ? g4 : 0);
+  int next = T < 16 ? T : 16;
+  const int stop = race ? 8 : 0;
+  UConst uc;
+  if constexpr (UNIFORM) uc = load_uconst(*QC_PARAMS_HERE(Pg));
+  for (;;) {
+    bool done;
+    if constexpr (UNIFORM) {
+      pin_uconst(uc);
+      done = L4.template iterate<Lane4::STEADY>(uc, eqp4, busy4);
+    } else {
+      done = L4.template iterate<Lane4::STEADY>(*QC_PARAMS_HERE(Pg), eqp4, busy4);
+    }
+    busy4 = busy4 & !done;
+    const unsigned run16 = (unsigned)(__builtin_amdgcn_ballot_w64(busy4) & 0xFFFFull);  // member 0 of the groups = lanes 0-15
+    const int nrun = __builtin_popcount(run16);
+    if (next < T) {
+      if (16 - nrun >= refill) {
+        if (holds && !busy4) push4(L4, rslot);
+        const unsigned free16 = ~run16 & 0xFFFFu;
+        const int t = next + __builtin_popcount(free16 & ((1u << g4) - 1u));
+        if (!busy4) {
+          holds = t < T;
+          if (holds) {
+            take(t);
+            busy4 = true;
+          }
+        }
+        next += __builtin_popcount(free16);
+        next = next < T ? next : T;
+      }
+      continue;
+    }
+    if (nrun <= stop) break;
+  }
+  if (holds && !busy4) push4(L4, rslot);
+  const unsigned run16 = (unsigned)(__builtin_amdgcn_ballot_w64(busy4) & 0xFFFFull);
+  const int nrun = __builtin_popcount(run16);
+  if (nrun == 0) {
+    QC_CLK_END(8);
+    return;
+  }
+  // race stage (as the one-fill kernels' tail): the <= 8 survivors are re-packed - through the drained list - each into TWO
+  // groups 8 lanes apart that continue with different drop rules (most negative multiplier / all negative multipliers);
+  // the first at the KKT point wins
+  {
+    double* rpk = list;
+    const int rank = __builtin_popcount(run16 & ((1u << g4) - 1u));
+    __builtin_amdgcn_wave_barrier();  // (this wave is alone by now; LDS operations of one wave stay in order)
+    if (busy4) repack_write(L4, rpk + rank * REPACK_RS, rslot, j4);
+    __builtin_amdgcn_wave_barrier();
+    LaneR LR;
+    Eqp4 eqpR(nullptr);
+    const int r = g4 & 7, sid = g4 >> 3;  // robot, strategy of this group
+    bool busyR = r < nrun;
+    const int rs = repack_read(Pg, LR, eqpR, rpk + (busyR ? r : 0) * REPACK_RS, j4);
+    LR.drop_all = sid == 1;
+    unsigned solved_mask = 0;
+    auto after = [&](bool fin) {
+      const int me = (busyR & fin & (LR.status == QC_SOLVED)) ? (1 << sid) : 0;
+      const int m = me | __builtin_amdgcn_update_dpp(0, me, 0x120 + 8, 0xF, 0xF, true);  // row_ror 8: the partner group
+      solved_mask |= (unsigned)m;
+      busyR = busyR & !fin & (solved_mask == 0);
+    };
+    while (__builtin_amdgcn_ballot_w64(busyR) != 0) {
+      if constexpr (UNIFORM) {
+        pin_uconst(uc);
+        after(LR.template iterate<LaneR::STEADY>(uc, eqpR, busyR));
+      } else {
+        after(LR.template iterate<LaneR::STEADY>(*QC_PARAMS_HERE(Pg), eqpR, busyR));
+      }
+    }
+    const int win = solved_mask ? __builtin_ctz(solved_mask) : 0;
+    if (r < nrun && sid == win) {
+      const uint32_t word = (uint32_t)group_or<4, true>((int)LR.word_bits()) | 0x80000000u;
+      CParams& P = *QC_PARAMS_HERE(Pg);
+      store_result<KIN, 1>(P, in, out, LR.idx, LR.stance, LR.status, LR.iters, word, LR.f, j4, lds.Rrows + 9 * rs, 1);
+    }
+  }
+  QC_CLK_END(8);
+}
+
 }  // namespace qc
 
 // =============================================================== host / C ABI
@@ -1071,6 +1324,10 @@ struct qc_handle {
   uint32_t last_word;  // qc_control(): working set of the previous call (hot start)
   bool has_last;
   hipStream_t stream;
+  int pair_override;  // MODE 3 (paired waves): -1 heuristic, 0 never, 1 whenever the form allows it
+  int pair_th;        // hand-over threshold (0: heuristic)
+  int pair_refill;    // free lane groups that trigger a refill (0: heuristic)
+  int pair_solo;      // 1: the last round of workgroups keeps each wave's stragglers in the wave (default), 0: pairs everywhere
 };
 
 #define QC_COMMA(...) __VA_ARGS__
@@ -1216,7 +1473,13 @@ static qc_kernel_fn kernel_for(int form, int G, int mode, bool kin, int minw = 2
   return mode ? kernel_of<EqpDiagW<true, 1>, 2, 1>(kin) : QC_MODE0(QC_COMMA(EqpDiagW<true, 1>));
 #undef QC_MODE0
 }
+typedef void (*qc_pair_kernel_fn)(const qc::DevParams*, long, qc::BatchIn, const uint32_t*, qc::BatchOut, int, int, int, unsigned);
+static qc_pair_kernel_fn pair_kernel_for(int form) {
+  using namespace qc;
+  return form == QC_FORM_UNIFORM ? (qc_pair_kernel_fn)balance_pair_kernel<EqpDiagW<true, 1>, false> : (qc_pair_kernel_fn)balance_pair_kernel<EqpDiagW<false, 1>, false>;
+}
 static size_t lds_for(int form, int G, int mode) {
+  if (mode == 3) return 0;  // (static LDS: Rwb rows, record list, two counters)
 
   const size_t stock = (size_t)qc::stock_doubles(qc::stock_slots(G, mode)) * sizeof(double);
   if (form == QC_FORM_DENSE) return stock + (G == 4 ? (size_t)qc::EqpDense4::X_DOUBLES : (size_t)78 * 64) * sizeof(double);
@@ -1238,6 +1501,8 @@ static long resident_workgroups(qc_handle* h, qc_kernel_fn fn, size_t lds) {
 }
 
 struct qc_launch_plan {
+  qc_pair_kernel_fn pfn;  // mode 3
+  int p_th, p_refill;
   qc_kernel_fn fn;
   size_t lds;
   unsigned blocks;
@@ -1260,6 +1525,32 @@ static int plan_launch(qc_handle* h, long n, bool kin, bool warm, qc_launch_plan
     G = n <= cap4 ? 4 : 1;
     if (h->group_override) G = h->group_override == 4 ? 4 : 1;
     if (G == 4 && (h->one_fill_override == 0 || h->chunk_override > 16)) G = 1;
+  }
+  lp->pfn = nullptr;
+  lp->p_th = lp->p_refill = 0;
+  // MODE 3 (paired waves): 6x6 forms, one lane per robot, batches of at least four rounds of one-fill workgroups (524 288
+  // robots): measured -5 % there and nothing below (profiles/r03_paired_waves.log) - with few rounds the consumer of two
+  // waves' stragglers is mostly a longer chain at the end of the launch.  (Not the joint_q variants: they always run as
+  // one-fill workgroups.)
+  if (form != QC_FORM_DENSE && G == 1 && !kin && h->chunk_override <= 0 && h->one_fill_override != 0) {
+    const long res1 = resident_workgroups(h, kernel_for(form, 1, 1, kin, h->min_waves), lds_for(form, 1, 1));
+    bool use_pair = n >= 4 * res1 * 64;
+    if (h->pair_override >= 0) use_pair = h->pair_override != 0;
+    if (use_pair) {
+      lp->pfn = pair_kernel_for(form);
+      lp->fn = nullptr;
+      lp->lds = 0;
+      lp->blocks = (unsigned)((n + 127) / 128);
+      lp->chunk = 128;
+      lp->refill_t = 0;
+      lp->G = 1;
+      lp->mode = 3;
+      lp->race = 1;
+      lp->resident = res1 / 2;
+      lp->p_th = h->pair_th > 0 ? (h->pair_th < qc::PAIR_CAP ? h->pair_th : qc::PAIR_CAP) : 24;
+      lp->p_refill = h->pair_refill > 0 ? h->pair_refill : 4;
+      return QC_OK;
+    }
   }
   const long rpw = 64 / G;  // robots per wave fill
   const bool can_one_fill = true;
@@ -1493,6 +1784,10 @@ int qc_create(const qc_params* p, int device, qc_handle** out) {
   h->wave_slots_override = 0;
   h->min_waves = 2;
   h->race_override = -1;
+  h->pair_override = -1;
+  h->pair_th = 0;
+  h->pair_refill = 0;
+  h->pair_solo = 1;
   h->n_occ = 0;
   if (hipSetDevice(device) != hipSuccess || hipMalloc((void**)&h->d_params, sizeof(qc::DevParams)) != hipSuccess ||
       hipMemcpy(h->d_params, &h->dp, sizeof(qc::DevParams), hipMemcpyHostToDevice) != hipSuccess) {
@@ -1519,6 +1814,10 @@ int qc_set_tuning(qc_handle* h, const char* key, double value) {
     h->dp.tail_race = (value < 0 || value >= 2) ? 1 : 0;
     params = true;
   }
+  else if (k == "pair") h->pair_override = value < 0 ? -1 : (value != 0 ? 1 : 0);
+  else if (k == "pair_th") h->pair_th = value > 0 ? (int)value : 0;
+  else if (k == "pair_refill") h->pair_refill = value > 0 ? (int)value : 0;
+  else if (k == "pair_solo") h->pair_solo = value != 0 ? 1 : 0;
   else if (k == "min_waves") h->min_waves = value > 2 ? (int)value : 2;
   else if (k == "refill_t") h->refill_t = value > 0 ? (int)value : 16;
   else if (k == "rounds_cold") h->rounds_cold = value;
@@ -1555,7 +1854,7 @@ int qc_query_launch(qc_handle* h, size_t n, int kin, int warm, qc_launch_info* o
   out->strategies = lp.race;
   out->chunk = lp.chunk;
   out->blocks = lp.blocks;
-  out->resident_workgroups = resident_workgroups(h, lp.fn, lp.lds);
+  out->resident_workgroups = lp.mode == 3 ? lp.resident : resident_workgroups(h, lp.fn, lp.lds);
   out->lds_bytes = (int64_t)lp.lds;
   return QC_OK;
 }
@@ -1592,6 +1891,14 @@ int qc_control_batch(qc_handle* h, size_t n, const qc_batch_in* in, const uint32
   qc_launch_plan lp;
   const int rc = plan_launch(h, (long)n, kin, warm != nullptr, &lp);
   if (rc != QC_OK) return rc;
+  if (lp.mode == 3) {
+    // the last round of workgroups (those behind which nothing waits for a slot) runs solo
+    const long solo_from = h->pair_solo == 0 ? (long)lp.blocks : ((long)lp.blocks > lp.resident ? (long)lp.blocks - lp.resident : 0);
+    lp.pfn<<<dim3(lp.blocks), dim3(128), 0, (hipStream_t)stream>>>(h->d_params, (long)n, bi, warm, bo, lp.p_th, lp.p_refill,
+                                                                  h->dp.tail_race && warm == nullptr ? 1 : 0, (unsigned)solo_from);
+    QC_HIP(hipGetLastError());
+    return QC_OK;
+  }
   lp.fn<<<dim3(lp.blocks), dim3(64), lp.lds, (hipStream_t)stream>>>(h->d_params, (long)n, bi, warm, bo, lp.chunk, lp.refill_t);
   QC_HIP(hipGetLastError());
   return QC_OK;

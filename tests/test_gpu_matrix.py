@@ -2,7 +2,8 @@
 
 The planner (plan_launch, qc_balance.hip) chooses by formulation (uniform 6x6 / general 6x6 / dense 12x12),
 lanes per robot (1 / 2 / 4) and kernel mode (0 persistent waves with lane refill, 1 one fill per wave, 2 one fill
-with register-resident constants).  Each test forces one branch with qc_set_tuning, checks through qc_query_launch
+with register-resident constants, 3 paired waves: two one-lane waves per workgroup, the last to arrive finishes both
+waves' stragglers from a list in LDS).  Each test forces one branch with qc_set_tuning, checks through qc_query_launch
 that this branch is the one that runs, and compares with the C oracle on config-3 inputs (mixed 2/3/4-foot contact
 states), cold and warm-started; the joint_q / joint_tau (KIN) instantiations run the fused tick against the oracle's
 composition.  Cold runs of all forms must also take the same working-set path (identical iteration counts).
@@ -27,6 +28,7 @@ for form in ("uniform", "general"):
     CASES += [(form, 1, 1, dict(group=1, one_fill=1), 8200),  # ragged: the last wave holds 8 robots
               (form, 2, 1, dict(group=2, one_fill=1), 8200),  # ragged: the last wave holds 8 robots
               (form, 4, 1, dict(group=4, one_fill=1, race=0), 20480 if form == "uniform" else 8192)]
+    CASES += [(form, 1, 3, dict(group=1, pair=1), 8200 + 64 + 13)]  # paired waves: 65 workgroups, the last one with a ragged second wave
     if PERSISTENT_6X6:
         CASES += [(form, 1, 0, dict(group=1, chunk=256), 8192), (form, 2, 0, dict(group=2, chunk=256), 8192), (form, 4, 0, dict(group=4, chunk=128), 8192)]
 CASES += [("uniform", 4, 2, dict(group=4, one_fill=1, race=0), 8192),
@@ -124,7 +126,7 @@ def test_kernel_instantiation_vs_oracle(q, form, G, mode, tune, n, start):
 
 # every one-fill branch, every G > 1 branch, both dense widths (the one-lane persistent 6x6 kernels with joint_q spill
 # 532 B per lane and are never planned: kin batches always run as one-fill workgroups)
-KIN_CASES = [c for c in CASES if not (c[0] != "dense" and c[1] == 1 and c[2] == 0)]
+KIN_CASES = [c for c in CASES if not (c[0] != "dense" and c[1] == 1 and c[2] == 0) and c[2] != 3]  # (mode 3 has no joint_q variant)
 
 
 @pytest.mark.parametrize("form,G,mode,tune,n", KIN_CASES, ids=[f"kin-{f}-G{g}-mode{m}" for f, g, m, _, _ in KIN_CASES])
@@ -198,16 +200,20 @@ def test_iteration_cap_and_bad_inputs_agree_across_widths(q, cap):
     b["x"][bad[::2], 1] = np.nan
     b["Rwb"][bad[1::2], 4] = np.inf
     outs = {}
-    for g in (4, 2, 1):
-        ctl = q.BalanceController.from_params(P, max_iter=cap).set_tuning(group=g, one_fill=1, race=0, clamp_steps=1)  # one strategy, one start: the widths must agree exactly
-        assert ctl.query_launch(n)["lanes_per_robot"] == g
+    for g in (4, 2, 1, "pair"):
+        ctl = q.BalanceController.from_params(P, max_iter=cap).set_tuning(group=1 if g == "pair" else g, one_fill=1, race=0, clamp_steps=1)  # one strategy, one start: the widths must agree exactly
+        if g == "pair":  # the paired-waves kernel (mode 3): the cap may strike in the producer or in the list's consumer
+            ctl.set_tuning(pair=1)
+            assert ctl.query_launch(n)["mode"] == 3
+        else:
+            assert ctl.query_launch(n)["lanes_per_robot"] == g
         outs[g] = ctl.control_batch_host(b, want_iterations=True, want_active_set=True)
     ref = outs[4]
     assert (ref["status"][bad] == 3).all() and np.all(ref["grf_body"][bad] == 0.0)
     capped = ref["status"] == 1
     assert capped.any() if cap < 9 else True
     assert np.all(ref["grf_body"][capped] == 0.0) and (ref["iterations"][capped] == cap).all()
-    for g in (2, 1):
+    for g in (2, 1, "pair"):
         o = outs[g]
         assert np.array_equal(o["status"], ref["status"]), g
         assert np.array_equal(o["iterations"], ref["iterations"]), g

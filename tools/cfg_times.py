@@ -28,7 +28,9 @@ def outs(n, warm):
     if warm: o["active_set"] = torch.empty((n,), dtype=torch.int32, device="cuda")
     return o
 row = []
-for name, kind, n in (("cfg3", "cold", 65536), ("cfg4", "warm", 262144), ("cfg5s", "cold", 262144), ("1M", "cold", 1048576), ("2M", "cold", 2097152)):
+CASES = [("cfg3", "cold", 65536), ("cfg4", "warm", 262144), ("cfg5s", "cold", 262144), ("1M", "cold", 1048576), ("2M", "cold", 2097152)]
+CASES += [(a, "cold" if a[0] == "N" else "warm", int(a[1:])) for a in sizes if a[0] in "NW" and a[1:].isdigit()]  # N393216 = cold, W524288 = warm-started
+for name, kind, n in CASES:
     if sizes and name not in sizes: continue
     nsets = max(1, (512 << 20) // (488 * n) + 1) if n <= 262144 else 1
     ctl = q.BalanceController.from_params(P).set_tuning(**tune)
