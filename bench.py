@@ -310,7 +310,7 @@ def pmc_traffic(cfg, n, sha, kernel):
     import glob
 
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_cfg{cfg}.json"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_cfg{cfg}*.json"))):  # (r03_cfg5.json = the shard, r03_cfg5_n1.json = the whole batch)
         try:
             d = json.load(open(f))
             bl = d.get("bench_line", {})
@@ -561,6 +561,7 @@ def main():
             other["config5_n1"] = {"robots": CONFIG5_TOTAL, "solved_fraction": r["solved"] / CONFIG5_TOTAL,
                                    "cold_cache": rates(r, "cold", CONFIG5_TOTAL, 10, BYTES_PER_ROBOT_COLD),
                                    "what": "N = 1 point of the strong-scaling curve that `bench.py --gpus N` (N > 1) continues"}
+            attach_pmc(other["config5_n1"], 5, CONFIG5_TOTAL, sha, ctl.kernel_name)
             del r
             torch.cuda.empty_cache()
             r = run_config(ctl, q, 2, CONFIG_N[2], 0, k, 3, None, device, fused=True, protocols=("warm",))

@@ -1158,10 +1158,7 @@ __global__ __launch_bounds__(128, 2) void balance_pair_kernel(const DevParams* _
     if (lane == 0) arrived = __hip_atomic_fetch_add(&lds.arrived, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
     arrived = __builtin_amdgcn_readfirstlane(arrived);
   }
-  if (arrived == 0) {
-    QC_CLK_END(8);
-    return;
-  }
+  if (arrived == 0) return;  // (no clock hook here: the development harnesses' end-of-kernel hooks may hold a barrier)
   const int T = __hip_atomic_load(list_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   if (T == 0) {
     QC_CLK_END(8);

@@ -14,7 +14,7 @@ while read -r CTRS; do
   i=$((i+1))
   timeout 300 rocprofv3 --pmc $CTRS -f csv -d $OUT/p$i -o run -- python $ROOT/bench.py --no-cpu-baseline --no-sweep --steps 12 --warmup 2 $ARGS > $OUT/p$i.log 2>&1
   f=$OUT/p$i/run_counter_collection.csv
-  if [ -f $f ]; then (head -1 $f; grep balance_kernel $f) > $f.tmp && mv $f.tmp $f; fi
+  if [ -f $f ]; then (head -1 $f; grep -E "balance_(pair_)?kernel" $f) > $f.tmp && mv $f.tmp $f; fi
   find $OUT/p$i -type f ! -name "run_counter_collection.csv" -delete 2>/dev/null
 done <<LIST
 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS

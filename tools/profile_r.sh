@@ -21,7 +21,7 @@ grep -h '"metric"' $OUT/stats.log | tail -1 > $OUT/bench_line.json
 find $OUT/stats -type f ! -name "run_kernel_stats.csv" -delete
 for p in pmc_fetch pmc_write pmc_sq pmc_lds; do
   f=$OUT/$p/run_counter_collection.csv
-  if [ -f $f ]; then (head -1 $f; grep balance_kernel $f) > $f.tmp && mv $f.tmp $f; fi
+  if [ -f $f ]; then (head -1 $f; grep -E "balance_(pair_)?kernel" $f) > $f.tmp && mv $f.tmp $f; fi
   find $OUT/$p -type f ! -name "run_counter_collection.csv" -delete
 done
 du -sh $OUT

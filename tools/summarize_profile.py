@@ -11,7 +11,7 @@ tag = sys.argv[1]
 src = os.path.join("gpurun_out", tag)
 dst = "profiles"
 os.makedirs(dst, exist_ok=True)
-K = "balance_kernel"
+K = "balance_"  # balance_kernel and balance_pair_kernel
 out = {"tag": tag}
 stats = list(csv.DictReader(open(os.path.join(src, "stats", "run_kernel_stats.csv"))))
 krows = [r for r in stats if K in r["Name"]]
