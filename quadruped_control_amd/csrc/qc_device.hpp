@@ -363,20 +363,20 @@ struct LegTrig {
   double s1, c1, s2, c2, s23, c23;
 };
 // sin and cos of a joint angle.  The device library's sincos() carries its huge-argument reduction (Payne-Hanek, six
-// v_trig_preop_f64 per call) inline and branch-free: ~150 instructions, 24 calls per robot in a fused tick (forward kinematics
-// in front, J^T behind).  Joint angles are a few radians: for |x| < 2^20 a three-constant Cody-Waite reduction by pi/2
-// (k pi/2 subtracted in two exact-product steps: 33 + 53 bits of pi/2) and the classic minimax kernels on [-pi/4, pi/4]
-// (odd degree 13 for the sine, even degree 14 for the cosine; coefficients as in the public-domain fdlibm kernels) give
-// both values to ~1 ulp in ~40 instructions; anything larger, or not finite, takes the library routine.
+// v_trig_preop_f64 per call) along: 24 calls per robot in a fused tick (forward kinematics in front, J^T behind), and even
+// kept behind a branch as a fallback it cost the joint_q kernels 5 us per 65 536 robots (code size, registers, scratch).
+// Joint angles are a few radians: a Cody-Waite reduction by pi/2 in two fused steps (33 + 53 bits of pi/2; the first product
+// is exact for k < 2^20 and rounded once - far below the kernels' error - up to 2^30) and the classic minimax kernels on
+// [-pi/4, pi/4] (odd degree 13 for the sine, even degree 14 for the cosine; coefficients as in the public-domain fdlibm
+// kernels) give both values to 1 ulp of 1 for |x| < 2^30 in ~40 instructions (tools/sincos_check.hip: max error 2.2e-16 against
+// libm over +-1e6 and next to multiples of pi/2).  |x| >= 2^30 rad - where neighbouring doubles are 2^-22 rad apart - and
+// non-finite angles give NaN (the reference's libm would still return some value in [-1, 1] for the former: INTEGRATION.md).
 QC_DEV void sincos_joint(double x, double* __restrict__ sn, double* __restrict__ cs) {
-  if (!(fabs(x) < 1048576.0)) {  // (also NaN / Inf: the library's answers)
-    sincos(x, sn, cs);
-    return;
-  }
+  const bool ok = fabs(x) < 1073741824.0;                            // (false for NaN too)
   const double fn = __builtin_rint(x * 6.36619772367581382433e-01);  // x * 2/pi
-  double r = __builtin_fma(-fn, 1.57079632673412561417e+00, x);     // pi/2, first 33 bits: the product is exact
+  double r = __builtin_fma(-fn, 1.57079632673412561417e+00, x);     // pi/2, first 33 bits
   r = __builtin_fma(-fn, 6.07710050650619224932e-11, r);            // pi/2 - that
-  const int n = (int)fn;
+  const int n = (int)(ok ? fn : 0.0);
   const double z = r * r;
   const double ps = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
                                   2.75573137070700676789e-06), -1.98412698298579493134e-04), 8.33333333332248946124e-03), -1.66666666666666324348e-01);
@@ -386,8 +386,9 @@ QC_DEV void sincos_joint(double x, double* __restrict__ sn, double* __restrict__
   const double c = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.0));
   const bool swap = n & 1;
   const double ss = swap ? c : s, cc = swap ? s : c;
-  *sn = (n & 2) ? -ss : ss;
-  *cs = ((n + 1) & 2) ? -cc : cc;
+  const double nan = __builtin_nan("");
+  *sn = ok ? ((n & 2) ? -ss : ss) : nan;
+  *cs = ok ? (((n + 1) & 2) ? -cc : cc) : nan;
 }
 QC_DEV LegTrig leg_trig(const double* __restrict__ q) {
   LegTrig t;
