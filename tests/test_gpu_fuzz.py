@@ -40,3 +40,36 @@ def test_planner_fuzz_20s(built):
 
     worst_tau, worst_p, state_mismatch_ticks, done = stress_fuzz_planner.run_campaign(runs=40, n=2048, ticks=60, budget_s=20.0)
     assert done >= 2 and state_mismatch_ticks == 0 and worst_tau < 1e-6 and worst_p < 1e-9, (worst_tau, worst_p, state_mismatch_ticks, done)
+
+
+def test_cross_form_parity_600k(built):
+    """tests/stress_parity.py under pytest: every formulation and lane-group width on the same 600 000 robots - the default
+    plan (paired waves at this size), one-fill workgroups (pair = 0), four lanes per robot, the general 6x6 and the dense
+    12x12 form - agree with each other to 1e-7 of max|GRF| and with the oracle (65 536-robot sample) to 1e-6."""
+    import numpy as np
+    import torch
+
+    import quadruped_control_amd as q
+    from oracle import c_oracle as O
+    from quadruped_control_amd import workloads as W
+
+    n = 600000
+    P = q.cheetah_params(0.6)
+    b = W.config3(n, seed=0x5EED00AA)
+    d = q.to_device(b)
+    res = {}
+    for name, tune in (("default", {}), ("one-fill", {"pair": 0}), ("four lanes", {"group": 4}), ("general 6x6", {"force_general": 1}),
+                       ("dense 12x12", {"force_dense": 1})):
+        ctl = q.BalanceController.from_params(P).set_tuning(**tune)
+        o = ctl.control_batch(d)
+        torch.cuda.synchronize()
+        assert int((o["status"] != 0).sum()) == 0, name
+        res[name] = o["grf_body"].cpu().numpy()
+    assert q.BalanceController.from_params(P).query_launch(n)["mode"] == 3
+    base = res["default"]
+    scale = np.maximum(1.0, np.abs(base).max(axis=1, keepdims=True))
+    for name, g in res.items():
+        assert np.max(np.abs(g - base) / scale) < 1e-7, name
+    idx = np.random.default_rng(0).choice(n, 65536, replace=False)
+    ref, st, _ = O.control_batch(P, {k: np.ascontiguousarray(v[idx]) for k, v in b.items()}, threads=16)
+    assert (st == 0).all() and np.max(np.abs(base[idx] - ref) / scale[idx]) < 1e-6
