@@ -39,11 +39,20 @@ if ROOT not in sys.path:
 
 BYTES_PER_ROBOT_COLD = 488   # 48 f64 + 4 B stance read; 12 f64 + 4 B status written
 BYTES_PER_ROBOT_WARM = 496   # + 4 B warm word read + 4 B active-set word written
+# SURVEY 8(f) ticks.  fused: joint_q replaces feet (same 384 B), joint_tau adds 96 B written.  full: no stance bytes; + gait phases
+# (32 B), joint_qdot (96 B) and the 224-byte swing-planning record read, + the record's 32 B of state words (leg_state, has_traj)
+# every tick rewrites - its 192 B of trajectory end points are written only on a stance -> swing edge, which the replayed
+# bench tick does not have after its first launch.
+BYTES_PER_ROBOT_FUSED = 584  # 384 + 4 read; 96 + 4 + 96 written
+BYTES_PER_ROBOT_FULL = 964   # 384 + 32 + 96 + 224 read; 96 + 4 + 96 + 32 written
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
 ROTATE_BYTES = 512 << 20     # the rotating sets of the cold-cache protocol cover more than this
 CONFIG5_TOTAL = 2097152
 
 CONFIG_N = {2: 4096, 3: 65536, 4: 262144, 5: 262144}  # robots per GPU (weak scaling / N = 1)
+TICK_DESC = {"fused": "; TICK: joint_q -> forward kinematics -> control() -> clamp(J^T f) -> joint_tau in the same launch (584 B/robot)",
+             "full": "; TICK: joint states + COM state + gait phases -> complete joint torque command (FK, contact rule, foothold planner, swing "
+                     "trajectories, IK, joint PD, QP, J^T) in the same launch (964 B/robot), contact states from trot phases"}
 CONFIG_DESC = {
     2: "config2: batch of {n} randomised COM poses/velocities per GPU, all 4 feet in contact, mu=0.6 pyramid cone, cold start",
     3: "config3: batch of {n} per GPU, mixed 2/3/4-foot contact states from trot/walk gait schedules, cold start",
@@ -75,18 +84,45 @@ def make_batch(cfg, n, start, seed_shift=0):
     return W.config5(n, start=start, seed=seed), None
 
 
-def rotation_sets(n, warm):
-    per = (BYTES_PER_ROBOT_WARM if warm else BYTES_PER_ROBOT_COLD) * n
+def bytes_per_robot(warm, fused=False):
+    if fused:
+        return BYTES_PER_ROBOT_FULL if fused == "full" else BYTES_PER_ROBOT_FUSED
+    return BYTES_PER_ROBOT_WARM if warm else BYTES_PER_ROBOT_COLD
+
+
+def rotation_sets(n, warm, fused=False):
+    per = bytes_per_robot(warm, fused) * n
     return 1 if per > ROTATE_BYTES else ROTATE_BYTES // per + 1
 
 
-def time_launches(launches, steps, warmup, dist=None):
+def make_tick_batch(cfg, n, start, fused, j=0):
+    """Inputs of the SURVEY 8(f) ticks for rotation set j.  fused = True: rows 1 + 2 (joint angles in - forward kinematics on
+    the device -, joint torques out: J^T f, clamped); "full": rows 3 + 4 too (contact state from gait phases, foothold
+    planner, swing trajectories, IK, joint PD)."""
+    import numpy as np
+
+    from quadruped_control_amd import workloads as W
+
+    batch, _ = make_batch(cfg, n, start, seed_shift=0x100 * j)
+    batch = W.with_joint_angles(batch, seed=0x5EED0006 + 0x100 * j, start=start)
+    if fused == "full":
+        batch = W.with_swing_references(batch, seed=0x5EED0007 + 0x100 * j, start=start)
+        idx = np.arange(start, start + n, dtype=np.uint64)
+        phase = np.fmod(np.array([0.0, 0.5, 0.5, 0.0])[None] + W.uniform(0x5EED0009 + 0x100 * j, idx, 3)[:, None], 1.0)
+        batch = {k: v for k, v in batch.items() if k not in ("stance", "swing_pos", "swing_vel")}
+        batch["gait_phase"] = np.ascontiguousarray(phase)
+    return batch
+
+
+def time_launches(launches, steps, warmup, dist=None, warm_all=False):
     """W untimed steps, then K timed steps bracketed by barrier + synchronize; step i runs launches[i % len].
     Returns (wall seconds for K steps, HIP-event seconds for K steps)."""
     import torch
 
     m = len(launches)
     w = max(warmup, min(m, 8))  # at least a few sets so that every code path is paged in
+    if warm_all:  # stateful ticks: every set has seen its first call (which plans all swinging legs) before the clock starts
+        w = max(w, m)
     for i in range(w):
         launches[i % m]()
     torch.cuda.synchronize()
@@ -117,19 +153,12 @@ def run_config(ctl, q, cfg, n, start, steps, warmup, dist=None, device=0, fused=
     dev = f"cuda:{device}"
     on_device = cfg in (3, 5) and not fused
     # the host copy of set 0 only feeds cpu_baseline; configs 3 / 5 make theirs on the device (below) and keep a small host sample
-    batch, prev = make_batch(cfg, min(n, 4096) if on_device else n, start)
-    if fused:  # SURVEY 8f rows 1+2: joint angles in (device FK), joint torques out (J^T f, clamped)
-        from quadruped_control_amd import workloads as W
-
-        batch = W.with_joint_angles(batch, start=start)
-        if fused == "full":  # rows 3+4 too: contact state from gait phases, swing planner/trajectories/IK/PD
-            batch = W.with_swing_references(batch, start=start)
-            idx = np.arange(start, start + n, dtype=np.uint64)
-            phase = np.fmod(np.array([0.0, 0.5, 0.5, 0.0])[None] + W.uniform(0x5EED0009, idx, 3)[:, None], 1.0)
-            batch = {k: v for k, v in batch.items() if k not in ("stance", "swing_pos", "swing_vel")}
-            batch["gait_phase"] = np.ascontiguousarray(phase)
+    if fused:
+        batch, prev = make_tick_batch(cfg, n, start, fused), None
+    else:
+        batch, prev = make_batch(cfg, min(n, 4096) if on_device else n, start)
     is_warm = prev is not None
-    sets = rotation_sets(n, is_warm) if ("cold" in protocols and not fused) else 1
+    sets = rotation_sets(n, is_warm, fused) if "cold" in protocols else 1
     # set 0 is the canonical workload; sets 1.. hold other robots of the same distribution (shifted seed)
     if cfg in (3, 5) and not fused:
         # config 3 / 5 inputs are generated on the device, per shard (same counter-based PRNG; the
@@ -144,13 +173,16 @@ def run_config(ctl, q, cfg, n, start, steps, warmup, dist=None, device=0, fused=
     else:
         hosts, prevs = [batch], [prev]
         for j in range(1, sets):
-            b, p = make_batch(cfg, n, start, seed_shift=0x100 * j)
+            if fused:
+                b, p = make_tick_batch(cfg, n, start, fused, j), None
+            else:
+                b, p = make_batch(cfg, n, start, seed_shift=0x100 * j)
             hosts.append(b)
             prevs.append(p)
         big = {k: torch.from_numpy(np.concatenate([h[k] for h in hosts])).to(dev) for k in batch}
         del hosts
-    if fused == "full":
-        big["swing_state"] = torch.from_numpy(q.new_swing_states(n).view("uint8").reshape(-1).copy()).to(dev)
+    if fused == "full":  # one planning record per robot of every set (in/out)
+        big["swing_state"] = torch.from_numpy(q.new_swing_states(sets * n).view("uint8").reshape(-1).copy()).to(dev)
     out = {"grf_body": torch.empty((sets * n, 12), dtype=torch.float64, device=dev),
            "status": torch.empty((sets * n,), dtype=torch.int32, device=dev)}
     warm = None
@@ -167,12 +199,12 @@ def run_config(ctl, q, cfg, n, start, steps, warmup, dist=None, device=0, fused=
     launches = []
     for j in range(sets):
         sl = slice(j * n, (j + 1) * n)
-        bj = {k: (v if k == "swing_state" else v[sl]) for k, v in big.items()}
+        bj = {k: (v[j * n * 224:(j + 1) * n * 224] if k == "swing_state" else v[sl]) for k, v in big.items()}
         oj = {k: v[sl] for k, v in out.items()}
         launches.append(ctl.plan_batch(bj, warm=None if warm is None else warm[sl], out=oj)[0])
     res = dict(n=n, sets=sets, batch=batch, warm=is_warm, out={k: v[:n] for k, v in out.items()})
     if "cold" in protocols:
-        res["cold"] = time_launches(launches, steps, warmup, dist)
+        res["cold"] = time_launches(launches, steps, warmup, dist, warm_all=fused == "full")
     if "warm" in protocols:
         res["warm_cache"] = time_launches(launches[:1], steps, warmup, dist)
     res["solved"] = int((out["status"][:n] == 0).sum().item())
@@ -190,6 +222,37 @@ def host_cores():
     except Exception:
         pass
     return max(1, n)
+
+
+def cpu_model():
+    """The host CPU as /proc/cpuinfo names it ("T and the CPU model are printed")."""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    import platform
+
+    return platform.processor() or platform.machine() or "unknown"
+
+
+def oracle_build_flags():
+    """Compiler and flags the C oracle was built with, read from oracle/Makefile (what `make -C oracle liboracle.so` ran)."""
+    try:
+        txt = open(os.path.join(ROOT, "oracle", "Makefile")).read()
+        import re
+
+        cc = re.search(r"^CC \?= *(.*)$", txt, re.M).group(1).strip()
+        fl = re.search(r"^CFLAGS \?= *(.*)$", txt, re.M).group(1).strip()
+        cc = os.environ.get("CC", cc)
+        try:
+            ver = subprocess.run([cc, "-dumpfullversion"], capture_output=True, text=True, timeout=10).stdout.strip()
+        except Exception:
+            ver = ""
+        return f"{cc} {ver} {os.environ.get('CFLAGS', fl)}".replace("  ", " ")
+    except Exception:
+        return "unknown"
 
 
 def cpu_baseline(P, batch, budget_s=4.0):
@@ -236,7 +299,11 @@ def cpu_baseline(P, batch, budget_s=4.0):
     return {"value": reps * n / dt, "unit": "QPs/s", "cores": threads, "kind": "port",
             "sample": f"first {base} robots of the benchmark batch tiled x{tile} = {n} robots per call x {reps} calls, {threads} OpenMP threads, "
                       f"{dt:.1f} s wall; C restatement (textbook primal active set), not qpOASES",
-            "single_thread_value": one}
+            "single_thread_value": one,
+            # what the figure depends on besides the algorithm (it moved 5.4e5 -> 4.4e5 between rounds 2 and 3 on different host CPUs)
+            "cpu_model": cpu_model(), "threads": threads, "host_logical_cpus": os.cpu_count(),
+            "compiler": oracle_build_flags(),
+            "refinement": "off (the checker's long-double recomputation of the accepted point is not timed; decisions are the same)"}
 
 
 def batch_load_probe(q, P, device, nb=2097152, steps=10):
@@ -302,7 +369,7 @@ def host_boundary(ctl, q):
     return res
 
 
-def pmc_traffic(cfg, n, sha, kernel):
+def pmc_traffic(cfg, n, sha, kernel, tick=None):
     """HBM bytes per launch from a committed PMC pass of this workload AND these kernel sources
     (profiles/rNN_cfg<cfg>.json, produced by tools/profile_r.sh + tools/summarize_profile.py: separate --pmc
     FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per MI355X_MICROARCH.md).  None if no matching pass:
@@ -310,11 +377,13 @@ def pmc_traffic(cfg, n, sha, kernel):
     import glob
 
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_cfg{cfg}*.json"))):  # (r03_cfg5.json = the shard, r03_cfg5_n1.json = the whole batch)
+    pattern = f"r*_tick_{tick}*.json" if tick else f"r*_cfg{cfg}*.json"  # (r03_cfg5.json = the shard, r03_cfg5_n1.json = the whole batch)
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern))):
         try:
             d = json.load(open(f))
             bl = d.get("bench_line", {})
             if (bl.get("config", {}).get("robots_per_gpu") == n and bl.get("config", {}).get("kernel") == kernel
+                    and bl.get("config", {}).get("tick") == tick and bl.get("config", {}).get("config_id", cfg) == cfg
                     and bl.get("kernel_src_sha16") == sha and "traffic" in d):
                 best = (d["traffic"]["hbm_bytes_per_launch"], os.path.relpath(f, ROOT), d.get("valu"))
         except Exception:
@@ -322,11 +391,11 @@ def pmc_traffic(cfg, n, sha, kernel):
     return best
 
 
-def attach_pmc(target, cfg, n, sha, kernel):
+def attach_pmc(target, cfg, n, sha, kernel, tick=None):
     """roofline.traffic / roofline_valu of `target` (a bench line or an other_configs entry) from the committed,
     hash-matched PMC pass of that workload.  The HBM fraction is what the contract asks for; the bound that binds the
     solve is FP64 VALU issue, so that one travels next to it."""
-    tr = pmc_traffic(cfg, n, sha, kernel)
+    tr = pmc_traffic(cfg, n, sha, kernel, tick)
     if tr is None:
         return
     src = tr[1] + " (rocprofv3 --pmc passes of this workload on these kernel sources)"
@@ -377,6 +446,9 @@ def main():
     ap.add_argument("--probe-batch-load", action="store_true",
                     help="time the load -> assemble -> store phase alone (no solver iterations) on 2,097,152 robots "
                          "(done by default together with the sweep)")
+    ap.add_argument("--tick", choices=["fused", "full"], default=None,
+                    help="development / profiling: time the SURVEY 8(f) tick built around the QP instead of the QP alone - fused = joint_q -> "
+                         "FK -> control() -> J^T -> joint_tau; full = + contact rule, foothold planner, swing trajectories, IK, joint PD")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="development: qc_set_tuning override(s)")
     args = ap.parse_args()
 
@@ -453,7 +525,14 @@ def main():
     else:
         n = args.n or CONFIG_N[cfg]
         start = rank * n
-    res = run_config(ctl, q, cfg, n, start, args.steps, args.warmup, dist, device)
+
+    def _bounds(r):  # robots [lo, hi) of rank r, as every rank computes them for itself
+        if scaling == "strong":
+            return shard_bounds(total, r, world)
+        return r * n, (r + 1) * n
+
+    fused = {None: False, "fused": True, "full": "full"}[args.tick]
+    res = run_config(ctl, q, cfg, n, start, args.steps, args.warmup, dist, device, fused=fused)
 
     from quadruped_control_amd.sharding import reduce_counters
 
@@ -475,10 +554,10 @@ def main():
 
     if rank == 0:
         sha = kernel_src_sha16()
-        bytes_per = BYTES_PER_ROBOT_WARM if res["warm"] else BYTES_PER_ROBOT_COLD
+        bytes_per = bytes_per_robot(res["warm"], fused)
         kernel_s = res["cold"][1] / args.steps
         achieved = bytes_per * n / kernel_s / 1e9
-        info = ctl.query_launch(n, warm=res["warm"])
+        info = ctl.query_launch(n, kin=bool(fused), warm=res["warm"])
         line = {
             "metric": "friction-cone QPs/sec (12 vars, 4-foot stance) at 1/2/4/8 MI355X",
             "value": total_robots * args.steps / wall,
@@ -492,10 +571,12 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic" + (" (generated on the device, per shard)" if cfg in (3, 5) else ""),
-            "config": {"workload": CONFIG_DESC[cfg].format(n=n), "robots_per_gpu": n, "global_batch": total_robots,
+            "config": {"workload": CONFIG_DESC[cfg].format(n=n) + (TICK_DESC[args.tick] if args.tick else ""), "config_id": cfg, "tick": args.tick,
+                       "robots_per_gpu": n, "global_batch": total_robots,
                        "kernel": ctl.kernel_name, "lanes_per_robot": info["lanes_per_robot"], "kernel_mode": info["mode"],
                        "resident_workgroups": info["resident_workgroups"],
                        "parallelism": f"batch-shard x{world} (no data-path collective)",
+                       "shards": [list(_bounds(r)) for r in range(world)],
                        "cache_protocol": f"cold: the timed loop rotates through {res['sets']} distinct input/output sets "
                                          f"({res['sets'] * bytes_per * n / 2**20:.0f} MiB in total) so every launch reads its inputs from HBM"},
             "solved_fraction": solved_total / total_robots,
@@ -518,7 +599,7 @@ def main():
         if gather_s is not None:
             line["result_gather"] = {"bytes_per_rank": n * 96, "seconds": gather_s, "GBs_per_rank": n * 96 * (world - 1) / gather_s / 1e9,
                                      "what": "all-gather of the [n, 12] GRF blocks after the timed region (not part of value)"}
-        attach_pmc(line, cfg, n, sha, ctl.kernel_name)
+        attach_pmc(line, cfg, n, sha, ctl.kernel_name, tick=args.tick)
         if dist is not None:
             line["ranks"] = {"avg_kernel_us_min": k_min, "avg_kernel_us_max": k_max,
                              "allreduce_us": allreduce_s * 1e6, "backend": dist.get_backend(),
@@ -539,7 +620,7 @@ def main():
                                     "and is NOT the N = 1 point of this curve; n1_reference (or other_configs.config5_n1 of that line) is.")
             res = {"batch": None}
             del r1
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.tick:
             line["cpu_baseline"] = cpu_baseline(P, res["batch"])  # (configs 3 / 5: the first 4096 robots of the batch)
         del res
         torch.cuda.empty_cache()
@@ -564,17 +645,25 @@ def main():
             attach_pmc(other["config5_n1"], 5, CONFIG5_TOTAL, sha, ctl.kernel_name)
             del r
             torch.cuda.empty_cache()
-            r = run_config(ctl, q, 2, CONFIG_N[2], 0, k, 3, None, device, fused=True, protocols=("warm",))
-            other["config2_fused_tick"] = {"robots": CONFIG_N[2], "QPs_per_s": CONFIG_N[2] * k / r["warm_cache"][0],
-                                           "solved_fraction": r["solved"] / CONFIG_N[2],
-                                           "what": "joint_q -> forward kinematics -> control() -> clamp(J^T f) -> joint_tau in one launch (584 B/robot)"}
-            r = run_config(ctl, q, 3, CONFIG_N[3], 0, k, 3, None, device, fused="full", protocols=("warm",))
-            other["config3_full_tick"] = {"robots": CONFIG_N[3], "ticks_per_s": CONFIG_N[3] * k / r["warm_cache"][0],
-                                          "solved_fraction": r["solved"] / CONFIG_N[3],
-                                          "what": "joint states + COM state + gait phases -> complete joint torque command "
-                                                  "(FK, contact rule, foothold planner, swing trajectories, IK, joint PD, QP, J^T) in one launch"}
-            del r
-            torch.cuda.empty_cache()
+            # the ticks built around the QP, under the same cold-cache protocol as the hot path
+            for key, c, nn, fz, what in (
+                    ("config2_fused_tick", 2, CONFIG_N[2], True, "joint_q -> forward kinematics -> control() -> clamp(J^T f) -> joint_tau in one launch"),
+                    ("config3_full_tick", 3, CONFIG_N[3], "full", "joint states + COM state + gait phases -> complete joint torque command "
+                     "(FK, contact rule, foothold planner, swing trajectories, IK, joint PD, QP, J^T) in one launch"),
+                    ("full_tick_262144", 3, 262144, "full", "the same complete tick on 262,144 robots (two rounds of workgroups)")):
+                r = run_config(ctl, q, c, nn, 0, k, 3, None, device, fused=fz)
+                bp = bytes_per_robot(False, fz)
+                tk = "full" if fz == "full" else "fused"
+                e = {"robots": nn, "solved_fraction": r["solved_all_sets"] / (r["sets"] * nn), "sets": r["sets"], "bytes_per_robot": bp,
+                     "ticks_per_s": nn * k / r["cold"][0],
+                     "cold_cache": rates(r, "cold", nn, k, bp), "warm_cache": rates(r, "warm_cache", nn, k, bp), "what": what}
+                e["roofline"] = {"bound": "hbm", "achieved": e["cold_cache"]["hbm_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": e["cold_cache"]["hbm_GBs"] / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": bp * nn,
+                                 "avg_kernel_us": e["cold_cache"]["avg_kernel_us"]}
+                attach_pmc(e, c, nn, sha, ctl.kernel_name, tick=tk)
+                other[key] = e
+                del r
+                torch.cuda.empty_cache()
             line["other_configs"] = other
         if world == 1 and not args.no_sweep:
             line["host_boundary"] = host_boundary(ctl, q)
@@ -583,6 +672,23 @@ def main():
         print(json.dumps(line), flush=True)
 
     if dist is not None:
+        # Rank 0 may still be measuring n1_reference (generate the whole batch + 20 launches of it, possibly with a cold
+        # first kernel load) while the others are done: they wait for it on the rendezvous store under their OWN limit
+        # (QC_BENCH_FINAL_TIMEOUT_S, default 600 s) - not inside a collective, where the 60 s fail-fast timeout that guards
+        # group formation would end the run - and only then meet in the last barrier.
+        import datetime
+
+        final_limit = float(os.environ.get("QC_BENCH_FINAL_TIMEOUT_S", "600"))
+        try:
+            store = dist.distributed_c10d._get_default_store()
+            if rank == 0:
+                store.set("qc_bench_rank0_done", "1")
+            else:
+                store.wait(["qc_bench_rank0_done"], datetime.timedelta(seconds=final_limit))
+        except Exception as e:  # noqa: BLE001
+            print(f"bench.py: rank {rank}/{world}: rank 0 did not finish its result line within {final_limit:.0f} s "
+                  f"(QC_BENCH_FINAL_TIMEOUT_S) - {type(e).__name__}: {str(e).splitlines()[0] if str(e) else ''}", file=sys.stderr, flush=True)
+            os._exit(4)
         dist.barrier()
         dist.destroy_process_group()
 

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define QC_ABI_VERSION 4
+#define QC_ABI_VERSION 5
 
 /* Replaces the constructor arguments of BalanceController
  * (balance_controller.hpp:85-88; defaults in commander_node.cpp:289-334 and
@@ -41,7 +41,7 @@ typedef struct qc_params {
   double kd_p[3];  /* COM linear-velocity Kd                                */
   double kp_w[3];  /* COM orientation Kp                                    */
   double kd_w[3];  /* COM angular-velocity Kd                               */
-  int32_t max_iter; /* working-set recalculation cap; <=0 -> 200 (nWSR_, balance_controller.cpp:85) */
+  int32_t max_iter; /* working-set recalculation cap; <=0 -> 200 (nWSR_, balance_controller.cpp:85); at most QC_MAX_ITER_LIMIT */
   int32_t reserved;
 } qc_params;
 
@@ -150,6 +150,8 @@ typedef enum qc_status {
 #define QC_ERR_INVALID (-1) /* bad argument (see qc_last_error)  */
 #define QC_ERR_HIP (-2)     /* HIP runtime error                 */
 #define QC_ERR_NO_DEVICE (-3)
+#define QC_ERR_ABI (-4)     /* caller and library were built against different revisions of this header */
+#define QC_MAX_ITER_LIMIT 65535 /* largest recalculation cap (qc_params.max_iter, "max_iter" tuning key) */
 
 typedef struct qc_handle qc_handle;
 
@@ -201,6 +203,14 @@ const char* qc_last_error(void);
  * ("diagW-6x6-uniform", "diagW-6x6" or "dense-12x12"), and ABI version. */
 const char* qc_kernel_name(const qc_handle* h);
 int qc_abi_version(void);
+/* ABI v5.  Guard for callers compiled separately from the library: pass QC_ABI_VERSION, sizeof(qc_params),
+ * sizeof(qc_batch_in) and sizeof(qc_batch_out) as the CALLER's header defines them; anything but QC_OK (QC_ERR_ABI, with
+ * the two sides spelled out in qc_last_error) means the structs this library reads are not the ones the caller fills
+ * (qc_batch_in has grown with every revision and carries no size field) and no other entry point may be used.  The
+ * C++ adapter's constructor and the Python loader call it; qc_create does not need a device for it.
+ * (The reference's constructor contract, balance_controller.hpp:85-88, has no analogue: it is header-only C++.) */
+int qc_check_abi(int abi_version, size_t sizeof_params, size_t sizeof_batch_in, size_t sizeof_batch_out);
+#define QC_CHECK_ABI() qc_check_abi(QC_ABI_VERSION, sizeof(qc_params), sizeof(qc_batch_in), sizeof(qc_batch_out))
 
 /* ABI v4.  Which kernel instantiation a batch of n robots would run on (kin = joint_q given, warm = warm-start
  * words given): lanes per robot, kernel mode (0 persistent waves with lane refill, 1 one fill per wave, 2 one fill
@@ -224,12 +234,13 @@ int qc_query_launch(qc_handle* h, size_t n, int kin, int warm, qc_launch_info* o
 /* ABI v4.  Development / test interface: explicit overrides of the launch heuristics and solver constants (the
  * library reads NO environment variables).  Keys: "group" (lanes per robot: 0 = heuristic, 1, 2, 4), "one_fill"
  * (-1 heuristic, 0 persistent waves, 1 one-fill workgroups; the persistent kernels of the 6x6 forms exist only in
- * development builds, -DQC_PERSISTENT_6X6=1: elsewhere those forms always run as one-fill workgroups and 0 applies to the
- * one-lane dense form), "chunk" (robots per wave, 0 = heuristic; beyond one fill only where persistent kernels exist),
+ * development builds, -DQC_PERSISTENT_6X6=1: elsewhere 0 applies to the one-lane dense form and a launch of a 6x6 form
+ * with it fails with QC_ERR_INVALID), "chunk" (robots per wave, 0 = heuristic; beyond one fill only where persistent
+ * kernels exist - QC_ERR_INVALID at launch otherwise),
  * "wave_slots" (resident workgroups assumed, 0 = occupancy query), "refill_t", "rounds_cold", "rounds_warm",
  * "race" (-1 heuristic; 0 or 1: one strategy per robot; 2, 4: at most that many racing in the 4-lane one-fill kernels),
  * "pair" (-1 heuristic, 0 never, 1 whenever one lane per robot on a 6x6 form: the paired-waves kernel, mode 3), "pair_th"
- * (its hand-over threshold, <= 32), "pair_refill", "pair_solo" (0: pairs in the last round of workgroups too),
+ * (its hand-over threshold, <= 32), "pair_refill" (free lane groups that trigger a refill, 1 ... 16), "pair_solo" (0: pairs in the last round of workgroups too),
  * "force_general" / "force_dense" (run the more general formulation on weights that would allow the
  * specialised one; same minimiser), "clamp_steps" (clamp steps a cold-started robot takes before its first ratio test in
  * the one-fill kernels; 0 = the kernel's rule: five on one or two lanes per robot, one on four),

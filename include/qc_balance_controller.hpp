@@ -190,6 +190,8 @@ public:
     copy_to_real_t(kd_w, p.kd_w);
     p.max_iter = 200;  // nWSR_, balance_controller.cpp:85
     p.reserved = 0;
+    // this translation unit and the shared library must agree on the structs that cross the C ABI
+    if (QC_CHECK_ABI() != QC_OK) throw std::runtime_error(std::string("BalanceController: ") + qc_last_error());
     qc_handle* h = nullptr;
     if (qc_create(&p, device, &h) != QC_OK) throw std::runtime_error(std::string("BalanceController: ") + qc_last_error());
     handle_ = std::shared_ptr<qc_handle>(h, qc_destroy);

@@ -13,6 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("QC_LIB_PATH") or os.path.join(_HERE, "libqc_balance.so")  # QC_LIB_PATH: development builds (tools/)
 
 QC_OK = 0
+QC_ERR_ABI = -4
+ABI_VERSION = 5  # the revision of include/qc_balance.h these ctypes structures were written against
 STATUS_NAMES = {0: "solved", 1: "max_iter", 2: "infeasible", 3: "not_pd"}
 
 
@@ -51,7 +53,7 @@ class QcLaunchInfo(C.Structure):
 
 EXPORTS = ("qc_create", "qc_destroy", "qc_control_batch", "qc_control_batch_host", "qc_control",
            "qc_last_error", "qc_kernel_name", "qc_abi_version", "qc_default_kinematics", "qc_set_kinematics", "qc_set_gait", "qc_swing_state_init",
-           "qc_set_tuning", "qc_query_launch")
+           "qc_set_tuning", "qc_query_launch", "qc_check_abi")
 
 _lib = None
 
@@ -108,6 +110,13 @@ def load():
     lib.qc_set_tuning.restype = C.c_int
     lib.qc_query_launch.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(QcLaunchInfo)]
     lib.qc_query_launch.restype = C.c_int
+    lib.qc_check_abi.argtypes = [C.c_int, C.c_size_t, C.c_size_t, C.c_size_t]
+    lib.qc_check_abi.restype = C.c_int
+    # the structures above are hand-written mirrors of the header: a library built from another revision is refused here,
+    # before any of them crosses the boundary
+    rc = lib.qc_check_abi(ABI_VERSION, C.sizeof(QcParams), C.sizeof(QcBatchIn), C.sizeof(QcBatchOut))
+    if rc != QC_OK:
+        raise ImportError(f"{LIB_PATH}: {lib.qc_last_error().decode()}")
     _lib = lib
     return lib
 

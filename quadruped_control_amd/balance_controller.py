@@ -97,7 +97,9 @@ class BalanceController:
 
     def set_tuning(self, **kw):
         """Development / test interface (qc_set_tuning): explicit overrides of the launch heuristics, e.g.
-        set_tuning(group=4, one_fill=0, chunk=128, force_general=1).  The library reads no environment variables."""
+        set_tuning(group=2, one_fill=1, force_general=1, clamp_steps=1).  A request the build cannot honour - persistent waves
+        (one_fill=0, chunk beyond one fill) for a 6x6 form without -DQC_PERSISTENT_6X6=1 - makes the next launch or
+        query_launch() fail instead of silently running one-fill workgroups.  The library reads no environment variables."""
         for key, value in kw.items():
             rc = self._lib.qc_set_tuning(self._h, key.encode(), float(value))
             if rc != _lib.QC_OK:

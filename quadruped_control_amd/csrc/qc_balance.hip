@@ -130,8 +130,9 @@ struct Lane {
   //  * a robot that is finished WITHOUT being solved (QC_NOT_PD, the iteration cap, a racing group whose partner won)
   //    does keep moving f while C stays frozen - and nobody reads that f: store_result() writes zero forces for every
   //    status other than QC_SOLVED, and a racing loser never pushes (the winner's group does);
-  //  * the cap needs no per-lane bookkeeping: robots of one fill start together and `iters` counts wave-uniform
-  //    recalculations, so all of them reach max_iter in the same recalculation and the loop ends there.
+  //  * the cap is tested per lane (`iters >= P.max_iter` in the return value), so it holds for robots that did not start
+  //    together as well - the refilled lane groups of the paired-waves consumer, whose records carry their own count; in a
+  //    one-fill wave all robots happen to reach it in the same recalculation.
   // tests/test_gpu_matrix.py::test_iteration_cap_and_bad_inputs_agree_across_widths holds status, iteration count and the
   // (zero) forces of capped / bad robots equal across the lane-group widths.
   enum { MIXED = 0, FIRST = 1, STEADY = 2 };
@@ -1311,7 +1312,7 @@ struct qc_handle {
   int race_override;       // -1 heuristic; 0 / 1: no racing strategies; 2, 4: at most that many per robot
   int min_waves;           // development builds (QC_EXPERIMENTAL_OCC): register cap of the one-fill kernels, waves per SIMD
   // resident workgroups per kernel instantiation (hipOccupancyMaxActiveBlocksPerMultiprocessor x CUs), filled lazily
-  struct { qc_kernel_fn fn; size_t lds; long resident; } occ[40];
+  struct { const void* fn; size_t lds; long resident; } occ[40];
   int n_occ;
   // staging buffers for the host-pointer entry points
   void* stage;
@@ -1483,12 +1484,12 @@ static size_t lds_for(int form, int G, int mode) {
   return stock;
 }
 // workgroups of this kernel the device holds at once (registers, LDS and the 32-waves-per-CU cap, as the runtime sees them)
-static long resident_workgroups(qc_handle* h, qc_kernel_fn fn, size_t lds) {
+static long resident_workgroups(qc_handle* h, const void* fn, size_t lds, int threads = 64) {
   if (h->wave_slots_override > 0) return h->wave_slots_override;
   for (int i = 0; i < h->n_occ; i++)
     if (h->occ[i].fn == fn && h->occ[i].lds == lds) return h->occ[i].resident;
   int per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64, lds) != hipSuccess || per_cu <= 0) per_cu = 4;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, lds) != hipSuccess || per_cu <= 0) per_cu = 4;
   const long r = (long)per_cu * h->cus;
   if (h->n_occ < (int)(sizeof(h->occ) / sizeof(h->occ[0]))) {
     h->occ[h->n_occ].fn = fn; h->occ[h->n_occ].lds = lds; h->occ[h->n_occ].resident = r;
@@ -1512,7 +1513,7 @@ static int plan_launch(qc_handle* h, long n, bool kin, bool warm, qc_launch_plan
   const int form = !h->diag_w ? QC_FORM_DENSE : (h->uniform ? QC_FORM_UNIFORM : QC_FORM_GENERAL);
   int G = 1;
   const long simds = (long)h->cus * 4;
-  const long cap4 = resident_workgroups(h, kernel_for(form, 4, 1, kin, h->min_waves), lds_for(form, 4, 1)) * 16;
+  const long cap4 = resident_workgroups(h, (const void*)kernel_for(form, 4, 1, kin, h->min_waves), lds_for(form, 4, 1)) * 16;
   if (form != QC_FORM_DENSE) {
     G = n <= 16 * simds ? 4 : (n <= 32 * simds ? 2 : 1);
     if (h->group_override) G = h->group_override;
@@ -1525,12 +1526,17 @@ static int plan_launch(qc_handle* h, long n, bool kin, bool warm, qc_launch_plan
   }
   lp->pfn = nullptr;
   lp->p_th = lp->p_refill = 0;
+  // A request this build cannot honour is an error, not a silent fall-back to one-fill workgroups: the persistent (mode 0)
+  // kernels of the 6x6 forms exist only in -DQC_PERSISTENT_6X6=1 builds.
+  if (!QC_PERSISTENT_6X6 && form != QC_FORM_DENSE && (h->one_fill_override == 0 || h->chunk_override > 64 / G))
+    return fail(QC_ERR_INVALID, "qc_set_tuning: one_fill = 0 / a chunk beyond one fill asks for a persistent-wave kernel of a 6x6 form, which this "
+                                "build does not contain (compile with -DQC_PERSISTENT_6X6=1)");
   // MODE 3 (paired waves): 6x6 forms, one lane per robot, batches of at least four rounds of one-fill workgroups (524 288
   // robots): measured -5 % there and nothing below (profiles/r03_paired_waves.log) - with few rounds the consumer of two
   // waves' stragglers is mostly a longer chain at the end of the launch.  (Not the joint_q variants: they always run as
   // one-fill workgroups.)
   if (form != QC_FORM_DENSE && G == 1 && !kin && h->chunk_override <= 0 && h->one_fill_override != 0) {
-    const long res1 = resident_workgroups(h, kernel_for(form, 1, 1, kin, h->min_waves), lds_for(form, 1, 1));
+    const long res1 = resident_workgroups(h, (const void*)kernel_for(form, 1, 1, kin, h->min_waves), lds_for(form, 1, 1));
     bool use_pair = n >= 4 * res1 * 64;
     if (h->pair_override >= 0) use_pair = h->pair_override != 0;
     if (use_pair) {
@@ -1543,9 +1549,11 @@ static int plan_launch(qc_handle* h, long n, bool kin, bool warm, qc_launch_plan
       lp->G = 1;
       lp->mode = 3;
       lp->race = 1;
-      lp->resident = res1 / 2;
+      // two-wave workgroups of the pair kernel itself (its own registers and 26 KB of static LDS), not half of the one-fill figure
+      lp->resident = resident_workgroups(h, (const void*)lp->pfn, 0, 128);
       lp->p_th = h->pair_th > 0 ? (h->pair_th < qc::PAIR_CAP ? h->pair_th : qc::PAIR_CAP) : 24;
-      lp->p_refill = h->pair_refill > 0 ? h->pair_refill : 4;
+      // (1 ... 16 free lane groups: beyond 16 the refill test of the consumer could never fire and it would spin on a full list)
+      lp->p_refill = h->pair_refill > 0 ? (h->pair_refill < 16 ? h->pair_refill : 16) : 4;
       return QC_OK;
     }
   }
@@ -1554,7 +1562,7 @@ static int plan_launch(qc_handle* h, long n, bool kin, bool warm, qc_launch_plan
   bool one_fill = false;
   long resident = 0;
   if (can_one_fill) {
-    resident = resident_workgroups(h, kernel_for(form, G, 1, kin, h->min_waves), lds_for(form, G, 1));
+    resident = resident_workgroups(h, (const void*)kernel_for(form, G, 1, kin, h->min_waves), lds_for(form, G, 1));
     // (the one-lane dense kernel keeps round 1's thresholds: persistent waves beyond one round of cold workgroups)
     const double rounds = form == QC_FORM_DENSE ? (warm ? 6.0 : 1.0) : (warm ? h->rounds_warm : h->rounds_cold);
     one_fill = (double)n <= rounds * (double)(resident * rpw);
@@ -1585,7 +1593,7 @@ static int plan_launch(qc_handle* h, long n, bool kin, bool warm, qc_launch_plan
       chunk = 16 / race;
     }
   } else {
-    resident = resident_workgroups(h, kernel_for(form, G, 0, kin), lds_for(form, G, 0));
+    resident = resident_workgroups(h, (const void*)kernel_for(form, G, 0, kin), lds_for(form, G, 0));
     chunk = rpw;
     if (n > rpw * resident) chunk = ((n + resident - 1) / resident + 15) / 16 * 16;
     if (h->chunk_override > 0) chunk = h->chunk_override;
@@ -1606,6 +1614,19 @@ extern "C" {
 
 const char* qc_last_error(void) { return g_err.c_str(); }
 int qc_abi_version(void) { return QC_ABI_VERSION; }
+int qc_check_abi(int abi_version, size_t sizeof_params, size_t sizeof_batch_in, size_t sizeof_batch_out) {
+  // A caller compiled against another revision of include/qc_balance.h would hand over structs of another size
+  // (qc_batch_in has grown with every ABI revision and carries no size field): refuse it before any of them is read.
+  if (abi_version != QC_ABI_VERSION || sizeof_params != sizeof(qc_params) || sizeof_batch_in != sizeof(qc_batch_in) ||
+      sizeof_batch_out != sizeof(qc_batch_out)) {
+    char msg[256];
+    std::snprintf(msg, sizeof(msg), "qc_check_abi: caller built against ABI v%d (qc_params %zu B, qc_batch_in %zu B, qc_batch_out %zu B), library is "
+                  "ABI v%d (%zu / %zu / %zu B)", abi_version, sizeof_params, sizeof_batch_in, sizeof_batch_out, QC_ABI_VERSION,
+                  sizeof(qc_params), sizeof(qc_batch_in), sizeof(qc_batch_out));
+    return fail(QC_ERR_ABI, msg);
+  }
+  return QC_OK;
+}
 const char* qc_kernel_name(const qc_handle* h) {
   if (!h) return "";
   return h->diag_w ? (h->uniform ? "diagW-6x6-uniform" : "diagW-6x6") : "dense-12x12";
@@ -1678,6 +1699,8 @@ int qc_create(const qc_params* p, int device, qc_handle** out) {
   // The cone rows of the reference are two-sided with +-1e6 on the far side (BC.cpp:296-301: -1e6 <= fx - mu fz <= 0, ...).
   // Inside the cone |fx -+ mu fz| <= 2 mu fz <= 2 mu fzmax, so those sides cannot bind - and this solver does not carry
   // them - as long as 2 mu fzmax < 1e6.  Parameters beyond that would make the reference's QP a different one: refused.
+  // (the hand-over records of the re-packed tails carry the recalculation count in 16 bits)
+  if (p->max_iter > QC_MAX_ITER_LIMIT) return fail(QC_ERR_INVALID, "qc_create: max_iter must be <= 65535");
   if (!(2.0 * p->mu * p->fzmax < 1.0e6))
     return fail(QC_ERR_INVALID, "qc_create: need 2 * mu * fzmax < 1e6 (the +-1e6 sides of the reference's cone rows, balance_controller.cpp:296-301, are not carried)");
   for (int i = 0; i < 6; i++)
@@ -1827,6 +1850,7 @@ int qc_set_tuning(qc_handle* h, const char* key, double value) {
     h->uniform = h->cfg_uniform && !h->force_general;
   } else if (k == "tol_d") { h->dp.tol_d = value; params = true; }
   else if (k == "max_iter") {  // <= 0: back to the handle's own cap (qc_params.max_iter)
+    if (value > (double)QC_MAX_ITER_LIMIT) return fail(QC_ERR_INVALID, "qc_set_tuning: max_iter must be <= 65535");
     h->probing = false;
     h->dp.max_iter = value > 0 ? (int)value : h->cfg_max_iter; params = true;
   }
@@ -1851,7 +1875,7 @@ int qc_query_launch(qc_handle* h, size_t n, int kin, int warm, qc_launch_info* o
   out->strategies = lp.race;
   out->chunk = lp.chunk;
   out->blocks = lp.blocks;
-  out->resident_workgroups = lp.mode == 3 ? lp.resident : resident_workgroups(h, lp.fn, lp.lds);
+  out->resident_workgroups = lp.mode == 3 ? lp.resident : resident_workgroups(h, (const void*)lp.fn, lp.lds);
   out->lds_bytes = (int64_t)lp.lds;
   return QC_OK;
 }

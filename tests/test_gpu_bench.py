@@ -90,6 +90,33 @@ def test_bench_self_launch_two_ranks(built):
     _check_two_rank_line(_last_json(r.stdout), 65536)
 
 
+def test_bench_eight_ranks_before_the_eight_gpus(built):
+    """The run the driver issues on an 8-GPU node - `python bench.py --gpus 8`, self-launched - executed with eight real
+    ranks on this box's single GPU (QC_BENCH_ONE_DEVICE: all ranks on cuda:0, gloo for the barrier / counter reduction):
+    the whole line must come out - global batch, eight contiguous equal shards, every robot solved, n1_reference measured
+    by rank 0 while seven ranks wait under their own (long) limit, scaling_efficiency, per-rank kernel times, the gather."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(QC_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", QC_BENCH_TIMEOUT_S="120")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "8", "--steps", "10", "--warmup", "2", "--scaling", "strong", "--robots", "16384",
+                        "--gather-results"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, (r.stderr + r.stdout)[-3000:]
+    d = _last_json(r.stdout)
+    for k in CONTRACT:
+        assert k in d, k
+    total = 8 * 16384
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["config"]["global_batch"] == total and d["config"]["robots_per_gpu"] == 16384
+    assert d["config"]["shards"] == [[k * 16384, (k + 1) * 16384] for k in range(8)]
+    assert d["config"]["workload"].startswith("config5") and d["solved_fraction"] == 1.0
+    assert abs(d["value"] - total / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    ref = d["n1_reference"]
+    assert ref["robots"] == total and ref["solved_fraction"] == 1.0 and ref["value"] > 0
+    assert abs(d["scaling_efficiency"] - d["value"] / (8 * ref["value"])) < 1e-12
+    rk = d["ranks"]
+    assert 0 < rk["avg_kernel_us_min"] <= rk["avg_kernel_us_max"] and rk["backend"] == "gloo"
+    assert d["result_gather"]["bytes_per_rank"] == 16384 * 96 and d["result_gather"]["seconds"] > 0
+    assert "cpu_baseline" not in d and "roofline" in d
+
+
 def test_bench_missing_rank_fails_fast(built):
     """A rank that never joins: the ranks that did start end with a one-line diagnostic and a non-zero exit code after
     QC_BENCH_TIMEOUT_S, instead of waiting out the collective library's own (ten-minute) timeout."""

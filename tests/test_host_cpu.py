@@ -20,7 +20,44 @@ def test_abi_exports_match_header(built):
     from quadruped_control_amd import _lib
 
     assert set(_lib.EXPORTS) == declared
-    assert _lib.load().qc_abi_version() == 4
+    assert _lib.load().qc_abi_version() == _lib.ABI_VERSION == 5
+    m = re.search(r"#define QC_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "qc_balance.h")).read())
+    assert int(m.group(1)) == _lib.ABI_VERSION
+
+
+def test_abi_check_refuses_a_caller_built_against_another_revision(built):
+    """qc_batch_in has grown with every ABI revision and carries no size field, so an old caller
+    against a new .so would have its struct read past the end.  qc_check_abi (called by _lib.load() and by the C++
+    adapter's constructor) refuses the pair before any struct crosses the boundary; needs no device."""
+    from quadruped_control_amd import _lib
+
+    lib = _lib.load()  # (has already passed the check with this package's own structures)
+    sizes = (ctypes.sizeof(_lib.QcParams), ctypes.sizeof(_lib.QcBatchIn), ctypes.sizeof(_lib.QcBatchOut))
+    assert lib.qc_check_abi(_lib.ABI_VERSION, *sizes) == _lib.QC_OK
+    assert lib.qc_check_abi(_lib.ABI_VERSION - 1, *sizes) == _lib.QC_ERR_ABI  # an ABI v4 caller
+    assert "ABI v4" in _lib.last_error() and "ABI v5" in _lib.last_error()
+    assert lib.qc_check_abi(_lib.ABI_VERSION, sizes[0], sizes[1] - 8, sizes[2]) == _lib.QC_ERR_ABI  # ABI v2's qc_batch_in (no gait_dt)
+    assert lib.qc_check_abi(_lib.ABI_VERSION, sizes[0], sizes[1], sizes[2] - 8) == _lib.QC_ERR_ABI  # ABI v1's qc_batch_out (no joint_tau)
+    # the adapter and the loader do call it
+    assert "QC_CHECK_ABI()" in open(os.path.join(ROOT, "include", "qc_balance_controller.hpp")).read()
+    assert "qc_check_abi(ABI_VERSION" in open(os.path.join(ROOT, "quadruped_control_amd", "_lib.py")).read()
+
+
+def test_build_does_not_need_the_oracle(built, tmp_path, monkeypatch):
+    """the product's build() must not fail because the test infrastructure is absent or broken -
+    the oracle build is best-effort (a warning), the HIP library and the package import are not."""
+    import importlib
+    import warnings
+
+    import __graft_entry__ as g
+
+    importlib.reload(g)
+    monkeypatch.setattr(g, "ORACLE_DIR", str(tmp_path / "no_oracle_here"))
+    monkeypatch.setenv("QC_BUILD_REUSE", "1")  # (reuse the up-to-date in-tree library: this test is about the oracle leg)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        g.build()
+    assert any("oracle" in str(x.message) for x in w), [str(x.message) for x in w]
 
 
 def test_param_struct_layout_matches_c():

@@ -62,6 +62,12 @@ if "SQ_INSTS_VALU" in counters and krows and "bench_line" in out:
                    "issue_frac": counters["SQ_INSTS_VALU"] * 4.0 / (1024.0 * cycles), "simds": 1024, "clock_ghz": 2.4, "cycles_per_wave_inst": 4,
                    "kernel_ns": kernel_ns, "rocprof_avg_ns": float(main["AverageNs"])}
     out["valu"]["insts_valu_per_robot"] = counters["SQ_INSTS_VALU"] / robots  # wave-instructions per robot (a wave-instruction serves up to 64 lanes)
+    # mean resident waves per SIMD over the launch: SQ_WAVE_CYCLES (quad-cycles a wave is resident, summed over waves; the SQ_* cycle
+    # counters tick once per four clocks, MI355X_MICROARCH.md) / (1024 SIMDs x the launch's quad-cycles)
+    if counters.get("SQ_WAVE_CYCLES"):
+        out["valu"]["resident_waves_per_simd"] = counters["SQ_WAVE_CYCLES"] / (1024.0 * cycles / 4.0)
+        if counters.get("SQ_WAIT_INST_ANY"):
+            out["valu"]["wait_inst_any_frac_of_wave_time"] = counters["SQ_WAIT_INST_ANY"] / counters["SQ_WAVE_CYCLES"]
 json.dump(out, open(os.path.join(dst, tag + ".json"), "w"), indent=1)
 with open(os.path.join(dst, tag + ".md"), "w") as f:
     f.write(f"# rocprofv3 summary `{tag}`\n\n")
@@ -84,6 +90,9 @@ with open(os.path.join(dst, tag + ".md"), "w") as f:
         f.write(f"* {v['insts_valu_per_launch']:.0f} VALU wave-instructions per launch = {v['insts_valu_per_robot']:.2f} per robot"
                 + (f" = {v['wave_insts_per_wave']:.0f} per wave" if v["wave_insts_per_wave"] else "") + "\n")
         f.write(f"* issue fraction = insts x 4 cycles / (1024 SIMDs x {v['kernel_ns']:.0f} ns x 2.4 GHz) = **{v['issue_frac']:.3f}**\n")
+        if "resident_waves_per_simd" in v:
+            f.write(f"* resident waves per SIMD (mean over the launch) = SQ_WAVE_CYCLES / (1024 SIMDs x kernel quad-cycles) = **{v['resident_waves_per_simd']:.2f}**"
+                    + (f"; SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES = {v['wait_inst_any_frac_of_wave_time']:.2f}" if "wait_inst_any_frac_of_wave_time" in v else "") + "\n")
     if "bench_line" in out:
         f.write("\n## bench line of the profiled run\n\n```\n" + json.dumps(out["bench_line"]) + "\n```\n")
 print(open(os.path.join(dst, tag + ".md")).read())
