@@ -48,7 +48,8 @@ enum { IN_B = 0, IN_R = 6, IN_FLAGS = 18, IN_IDX = 19, IN_PLANES = 20,
        OUT_F = 0, OUT_STAT = 12, OUT_WORD = 13, OUT_IDX = 14, OUT_PLANES = 15,
        STOCK_PLANES = IN_PLANES + OUT_PLANES };
 constexpr int stock_slots(int G, int MODE) { return MODE == 0 ? 64 : 64 / G; }
-constexpr int stock_doubles(int slots) { return ((STOCK_PLANES * (slots + 1) + 63) / 64) * 64; }
+constexpr int TASK_DOUBLES = 32;  // 256 one-byte (robot, leg) tasks of the torque pass, behind the planes
+constexpr int stock_doubles(int slots) { return ((STOCK_PLANES * (slots + 1) + TASK_DOUBLES + 63) / 64) * 64; }
 
 // RACE (mode-2 kernels of batches that leave most SIMDs idle): several lane groups solve the SAME robot with
 // different pivoting strategies and the first to reach the KKT point wins.  A strategy is (nclamp, drop_all):
@@ -334,36 +335,33 @@ struct Lane {
 // referenceStates(gait_map, bounds) (trajectory.cpp:308-344) CLEARS every stored trajectory and creates
 // those of the planned legs from p_start = Rwb foot + x (commander_node.cpp:456) and the planned foothold.
 template <int FPL, bool STR = false>
-QC_DEV void swing_plan(CParams& P, const BatchIn& in, long robot, int foot0, uint32_t stance) {
+QC_DEV void swing_plan(CParams& P, const BatchIn& in, long robot, int foot0, uint32_t stance, const RawState& St, const Wrench<FPL>& W,
+                       const TickExtra& X) {
   constexpr int GG = 4 / FPL;
   SwingState* S = in.swing_state + robot;
-  const bool first = S->leg_state[0] < 0;  // state_map_.empty()
+  const bool first = X.leg_state[0] < 0;  // state_map_.empty()
   int plan = 0;
-  int prev[FPL], had[FPL];
+  int had[FPL];
 #pragma unroll
   for (int i = 0; i < FPL; i++) {
-    prev[i] = S->leg_state[foot0 + i];
-    had[i] = S->has_traj[foot0 + i];
-    const bool swing_now = !((stance >> (foot0 + i)) & 1u);
-    if (swing_now && (first || prev[i] == 1)) plan |= 1 << i;
+    // (selects over the four fetched words: foot0 is a per-lane value in the lane-group layouts)
+    const int f = foot0 + i;
+    const int prev = f == 0 ? X.leg_state[0] : (f == 1 ? X.leg_state[1] : (f == 2 ? X.leg_state[2] : X.leg_state[3]));
+    had[i] = f == 0 ? X.has[0] : (f == 1 ? X.has[1] : (f == 2 ? X.has[2] : X.has[3]));
+    const bool swing_now = !((stance >> f) & 1u);
+    if (swing_now && (first || prev == 1)) plan |= 1 << i;
   }
   const bool any = group_or<GG, STR>(plan) != 0;
-  double R[9], x[3], xdot[3], w[3], xdot_d[3];
-  load9(in.Rwb, robot, R);
-  load3(in.x, robot, x);
-  load3(in.xdot, robot, xdot);
-  load3(in.w, robot, w);
-  load3(in.xdot_d, robot, xdot_d);
 #pragma unroll
   for (int i = 0; i < FPL; i++) {
     const int leg = foot0 + i;
     if ((plan >> i) & 1) {
-      double pb[3], fh[3];
-      leg_fk(P, leg, leg_trig(in.joint_q + 12 * robot + 3 * leg), pb);  // foot_actual_map, commander_node.cpp:383-384
-      plan_foothold(P, leg, R, x, xdot, w, xdot_d, pb, fh);
+      // foot_actual_map (commander_node.cpp:383-384) went through Rwb in the wrench assembly already: W.r[i] = Rwb foot_body
+      double fh[3];
+      plan_foothold(P, leg, St.R, St.x, St.xdot, St.w, St.xdotd, W.r[i], fh);
 #pragma unroll
       for (int r = 0; r < 3; r++) {
-        S->p_start[3 * leg + r] = R[3 * r] * pb[0] + R[3 * r + 1] * pb[1] + R[3 * r + 2] * pb[2] + x[r];  // :456
+        S->p_start[3 * leg + r] = W.r[i][r] + St.x[r];  // Rwb foot + x, :456
         S->p_final[3 * leg + r] = fh[r];
       }
     }
@@ -377,7 +375,7 @@ QC_DEV void swing_plan(CParams& P, const BatchIn& in, long robot, int foot0, uin
 // (`S`, `fp`: what fetch_state() read; `sw`: the robot's four LegState bytes if in.stance is given)
 template <bool KIN, int FPL, bool STR>
 QC_DEV uint32_t assemble_from_state(CParams& P, const BatchIn& in, long robot, int member, const RawState& S, const double (&fp)[3 * FPL], uint32_t sw,
-                                    Wrench<FPL>& W) {
+                                    const TickExtra& X, Wrench<FPL>& W) {
   constexpr int GG = 4 / FPL;
   const int foot0 = member * FPL;
   const double fin = wrench_from_state<FPL, KIN>(P, S, fp, foot0, W);
@@ -386,13 +384,13 @@ QC_DEV uint32_t assemble_from_state(CParams& P, const BatchIn& in, long robot, i
     stance = ((sw & 0xFFu) ? 1u : 0u) | ((sw & 0xFF00u) ? 2u : 0u) | ((sw & 0xFF0000u) ? 4u : 0u) | ((sw & 0xFF000000u) ? 8u : 0u);
   } else if (in.gait_phase) {
     // GaitScheduler::phase(), gait.cpp:125-134 (almost_equal = |a-b| < 1e-12, math/numerics.cpp:18-21)
-    const double duty = in.gait_duty ? in.gait_duty[robot] : P.stance_phase;
+    const double duty = in.gait_duty ? X.duty : P.stance_phase;
     stance = 0;
     double phs[4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) phs[i] = in.gait_phase[4 * robot + i];
+    for (int i = 0; i < 4; i++) phs[i] = X.ph[i];
     if (in.gait_dt) {  // GaitScheduler::update(dt), gait.cpp:113-123: the clock of this robot advances first
-      const double step = 1.0 / (P.t_swing + P.t_stance) * in.gait_dt[robot];
+      const double step = 1.0 / (P.t_swing + P.t_stance) * X.dt;
       double* wp = in.gait_phase + 4 * robot;
 #pragma unroll
       for (int i = 0; i < 4; i++) {
@@ -410,7 +408,7 @@ QC_DEV uint32_t assemble_from_state(CParams& P, const BatchIn& in, long robot, i
       stance |= (ge0 && le) ? (1u << i) : 0u;
     }
   }
-  if (KIN && in.swing_state) swing_plan<FPL, STR>(P, in, robot, foot0, stance);
+  if (KIN && in.swing_state) swing_plan<FPL, STR>(P, in, robot, foot0, stance, S, W, X);
   // non-finite inputs poison b, r or R: report QC_NOT_PD instead of iterating on NaNs
   const bool bad = group_or<GG, STR>(!(fin == 0.0) ? 1 : 0) != 0;
   if (bad) {
@@ -428,10 +426,12 @@ QC_DEV uint32_t assemble_robot(CParams& P, const BatchIn& in, long robot, int me
   // all loads first, back to back (see the one-lane fill in balance_kernel): one memory round trip instead of four
   const uint32_t sw = in.stance ? *reinterpret_cast<const uint32_t*>(in.stance + 4 * robot) : 0u;
   RawState S;
+  TickExtra X;
   double fp[3 * FPL];
+  fetch_extra<KIN>(in, robot, X);
   fetch_state<FPL, KIN>(in, robot, member * FPL, S, fp);
   asm volatile("" ::: "memory");
-  return assemble_from_state<KIN, FPL, STR>(P, in, robot, member, S, fp, sw, W);
+  return assemble_from_state<KIN, FPL, STR>(P, in, robot, member, S, fp, sw, X, W);
 }
 
 // FPL = 4: one lane assembles a whole robot (dense restock of a big batch);
@@ -456,8 +456,9 @@ QC_DEV void assemble_to_stock(CParams& P, const BatchIn& in, const uint32_t* __r
   }
 }
 
-// output transform, BC.cpp:218-232: fb = -Rwb^T fw for stance legs; optional torque map.  `fw` = world-frame forces of
-// the FPL feet from foot0 on; `member` 0 also writes the per-robot words.
+// output transform, BC.cpp:218-232: fb = -Rwb^T fw for stance legs.  `fw` = world-frame forces of
+// the FPL feet from foot0 on; `member` 0 also writes the per-robot words.  (The joint torques of the widened tick are the
+// torque pass's, below.)
 // `Rl` != nullptr: the robot's Rwb is parked in LDS (entry k at Rl[k * rstride]) by the wave's assembly phase - the one-lane
 // one-fill kernel keeps it there instead of reading the 72-byte row from global memory a second time.
 template <bool KIN, int FPL>
@@ -473,63 +474,13 @@ QC_DEV void store_result(CParams& P, const BatchIn& in, const BatchOut& out, lon
 #pragma unroll
   for (int i = 0; i < FPL; i++) {
     const bool st = ((stance >> (foot0 + i)) & 1u) && st_out == QC_SOLVED;
-    double f[3], fb[3];
+    double f[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) f[k] = fw[3 * i + k];
 #pragma unroll
     for (int r = 0; r < 3; r++) {
       const double v = -(R[r] * f[0] + R[3 + r] * f[1] + R[6 + r] * f[2]);
-      fb[r] = st ? v : 0.0;
-      o[3 * i + r] = fb[r];
-    }
-    if (KIN && out.joint_tau) {  // commander_node.cpp:511-526: tau = clamp(J^T f, tau_min, tau_max)
-      const bool stance_leg = (stance >> (foot0 + i)) & 1u;
-      const double* qp = in.joint_q + 12 * idx + 3 * (foot0 + i);
-      double tau[3];
-      bool emit = st;
-      if ((in.swing_pos || in.swing_state) && !stance_leg) {  // swing leg: IK + J^-1 + joint PD, commander_node.cpp:482-504
-        double sp[3], sv[3];
-        if (in.swing_state) {  // FootTrajectoryManager::referenceState(leg, phase), trajectory.cpp:360-388
-          const SwingState* S = in.swing_state + idx;
-          // written by this wave's assembly phase: read past the (possibly stale) vector L1
-          const int has = __hip_atomic_load(&S->has_traj[foot0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          double p0[3], pf[3];
-#pragma unroll
-          for (int r = 0; r < 3; r++) {
-            p0[r] = __hip_atomic_load(&S->p_start[3 * (foot0 + i) + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            pf[r] = __hip_atomic_load(&S->p_final[3 * (foot0 + i) + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-          const double ph = in.gait_dt ? __hip_atomic_load(in.gait_phase + 4 * idx + foot0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                       : in.gait_phase[4 * idx + foot0 + i];
-          track_swing(P, ph, p0, pf, sp, sv);
-          if (!has) sp[0] = sp[1] = sp[2] = sv[0] = sv[1] = sv[2] = 0.0;  // no trajectory: FootState() (:387)
-        } else {
-#pragma unroll
-          for (int r = 0; r < 3; r++) {
-            sp[r] = in.swing_pos[12 * idx + 3 * (foot0 + i) + r];
-            sv[r] = in.swing_vel[12 * idx + 3 * (foot0 + i) + r];
-          }
-        }
-        const double* xp = in.x + 3 * idx;
-        double pb[3], vb[3];
-#pragma unroll
-        for (int r = 0; r < 3; r++) {
-          pb[r] = R[r] * sp[0] + R[3 + r] * sp[1] + R[6 + r] * sp[2] - xp[r];  // Rwb^T pos - x (sic, :492)
-          vb[r] = R[r] * sv[0] + R[3 + r] * sv[1] + R[6 + r] * sv[2];          // Rwb^T vel (:493)
-        }
-        leg_swing_torque(P, foot0 + i, pb, vb, qp, in.joint_qdot + 12 * idx + 3 * (foot0 + i), tau);
-        emit = true;
-      } else {
-        leg_jt_force(P, foot0 + i, leg_trig(qp), fb, tau);
-      }
-      double* to = out.joint_tau + 12 * idx + 3 * (foot0 + i);
-#pragma unroll
-      for (int r = 0; r < 3; r++) {
-        // arma::clamp (commander_node.cpp:526) is two compares: a NaN torque (NaN joint state) stays NaN, as in
-        // the reference, instead of turning into a full-scale command the way fmin(fmax()) would make it
-        const double t = tau[r];
-        to[r] = emit ? (t < P.tau_min ? P.tau_min : (t > P.tau_max ? P.tau_max : t)) : 0.0;
-      }
+      o[3 * i + r] = st ? v : 0.0;
     }
   }
   if (member == 0) {
@@ -572,6 +523,128 @@ QC_DEV int restock(const DevParams* __restrict__ Pg, const BatchIn& in, const ui
   return k;
 }
 
+// ---- the torque pass of the widened tick (SURVEY 8f rows 1 + 4): joint_tau of the robots parked in the output stock ----------
+// commander_node.cpp:482-531: swing legs get IK -> J^-1 -> joint PD torques, stance legs tau = J^T f_body, all clamped.
+// A (robot, leg) pair is a TASK, and a wave's tasks are sorted by kind before any of them runs: the swing-leg tasks are
+// packed into consecutive lanes and executed together, then the stance-leg tasks.  Round 3 looped over the four legs with one
+// robot per lane and a per-lane `if (swing) ... else ...`: in a batch of mixed contact states every leg is swinging in SOME
+// lane, so every lane walked through IK + J^-1 + PD and through J^T four times - eight passes of code for what is, for a trot,
+// two passes of the swing chain and two of the stance map (the 64 robots of a wave hold ~128 tasks of each kind).
+// The lists (one byte per task: slot << 2 | leg; swing tasks from the front, stance tasks from the back of a 256-byte array
+// behind the stock planes) are built with ballots and mbcnt, leg-major, so neighbouring lanes still touch neighbouring robots.
+
+// the robot in `slot` of the output stock: index, stance word, status as store_result reports it, Rwb (from the wave's LDS
+// rows when the assembly parked it there)
+template <int SP>
+QC_DEV void task_robot(const BatchIn& in, const double* __restrict__ sout, int slot, const double* __restrict__ Rplanes, long& idx, uint32_t& stance,
+                       int& st_out, double (&R)[9]) {
+  idx = __double_as_longlong(sout[OUT_IDX * SP + slot]);
+  const unsigned long long sw = (unsigned long long)__double_as_longlong(sout[OUT_STAT * SP + slot]);
+  const unsigned long long ww = (unsigned long long)__double_as_longlong(sout[OUT_WORD * SP + slot]);
+  stance = (uint32_t)(ww >> 32);
+  st_out = (stance & 0x100u) ? (int)QC_NOT_PD : (int)(uint32_t)sw;
+  const double* Rp = in.Rwb + 9 * idx;
+#pragma unroll
+  for (int k = 0; k < 9; k++) R[k] = Rplanes ? Rplanes[k * SP + slot] : Rp[k];
+}
+QC_DEV void store_tau(CParams& P, const BatchOut& out, long idx, int leg, const double (&tau)[3], bool emit) {
+  double* to = out.joint_tau + 12 * idx + 3 * leg;
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    // arma::clamp (commander_node.cpp:526) is two compares: a NaN torque (NaN joint state) stays NaN, as in
+    // the reference, instead of turning into a full-scale command the way fmin(fmax()) would make it
+    const double t = tau[r];
+    to[r] = emit ? (t < P.tau_min ? P.tau_min : (t > P.tau_max ? P.tau_max : t)) : 0.0;
+  }
+}
+// stance leg (or a swing leg of a batch without swing references: zero torque): tau = clamp(J^T f_body), kinematics.cpp:219-231
+template <int SP>
+QC_DEV void stance_leg_task(CParams& P, const BatchIn& in, const BatchOut& out, const double* __restrict__ sout, int slot, int leg,
+                            const double* __restrict__ Rplanes) {
+  long idx; uint32_t stance; int st_out; double R[9];
+  task_robot<SP>(in, sout, slot, Rplanes, idx, stance, st_out, R);
+  const bool st = ((stance >> leg) & 1u) && st_out == QC_SOLVED;
+  double f[3], fb[3], tau[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) f[k] = sout[(OUT_F + 3 * leg + k) * SP + slot];
+#pragma unroll
+  for (int r = 0; r < 3; r++) fb[r] = st ? -(R[r] * f[0] + R[3 + r] * f[1] + R[6 + r] * f[2]) : 0.0;  // BC.cpp:218-232
+  const LegGeom g = leg_geom(P, leg);
+  leg_jt_force(g, leg_trig(in.joint_q + 12 * idx + 3 * leg), fb, tau);
+  store_tau(P, out, idx, leg, tau, st);
+}
+// swing leg: reference foot state -> IK -> J^-1 -> joint PD, commander_node.cpp:482-504; independent of the QP's status
+template <int SP>
+QC_DEV void swing_leg_task(CParams& P, const BatchIn& in, const BatchOut& out, const double* __restrict__ sout, int slot, int leg,
+                           const double* __restrict__ Rplanes) {
+  long idx; uint32_t stance; int st_out; double R[9];
+  task_robot<SP>(in, sout, slot, Rplanes, idx, stance, st_out, R);
+  double sp[3], sv[3];
+  if (in.swing_state) {  // FootTrajectoryManager::referenceState(leg, phase), trajectory.cpp:360-388
+    const SwingState* S = in.swing_state + idx;
+    // written by this wave's assembly phase: read past the (possibly stale) vector L1
+    const int has = __hip_atomic_load(&S->has_traj[leg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    double p0[3], pf[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      p0[r] = __hip_atomic_load(&S->p_start[3 * leg + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      pf[r] = __hip_atomic_load(&S->p_final[3 * leg + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const double ph = in.gait_dt ? __hip_atomic_load(in.gait_phase + 4 * idx + leg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                 : in.gait_phase[4 * idx + leg];
+    track_swing(P, ph, p0, pf, sp, sv);
+    if (!has) sp[0] = sp[1] = sp[2] = sv[0] = sv[1] = sv[2] = 0.0;  // no trajectory: FootState() (:387)
+  } else {
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      sp[r] = in.swing_pos[12 * idx + 3 * leg + r];
+      sv[r] = in.swing_vel[12 * idx + 3 * leg + r];
+    }
+  }
+  const double* xp = in.x + 3 * idx;
+  double pb[3], vb[3], tau[3];
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    pb[r] = R[r] * sp[0] + R[3 + r] * sp[1] + R[6 + r] * sp[2] - xp[r];  // Rwb^T pos - x (sic, :492)
+    vb[r] = R[r] * sv[0] + R[3 + r] * sv[1] + R[6 + r] * sv[2];          // Rwb^T vel (:493)
+  }
+  const LegGeom g = leg_geom(P, leg);
+  leg_swing_torque(P, g, pb, vb, in.joint_q + 12 * idx + 3 * leg, in.joint_qdot + 12 * idx + 3 * leg, tau);
+  store_tau(P, out, idx, leg, tau, true);
+}
+template <int SP>
+QC_DEV void torque_pass(const DevParams* __restrict__ Pg, const BatchIn& in, const BatchOut& out, const double* __restrict__ sout, int out_n, int lane,
+                        const double* __restrict__ Rplanes) {
+  unsigned char* const tl = reinterpret_cast<unsigned char*>(const_cast<double*>(sout) + OUT_PLANES * SP);  // (TASK_DOUBLES behind the planes)
+  const bool have_swing = in.swing_pos || in.swing_state;
+  const bool mine = lane < out_n;
+  uint32_t stance = 0xFu;
+  if (mine) stance = (uint32_t)((unsigned long long)__double_as_longlong(sout[OUT_WORD * SP + lane]) >> 32);
+  int ns = 0, nt = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const bool sw = mine && have_swing && !((stance >> i) & 1u);
+    const bool st = mine && !sw;
+    const unsigned long long ms = __builtin_amdgcn_ballot_w64(sw), mt = __builtin_amdgcn_ballot_w64(st);
+    const unsigned char code = (unsigned char)((lane << 2) | i);
+    if (sw) tl[ns + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(ms >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ms, 0))] = code;
+    if (st) tl[255 - nt - (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mt >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mt, 0))] = code;
+    ns += __builtin_popcountll(ms);
+    nt += __builtin_popcountll(mt);
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int t = lane; t < ns; t += 64) {
+    const int code = tl[t];
+    swing_leg_task<SP>(*QC_PARAMS_HERE(Pg), in, out, sout, code >> 2, code & 3, Rplanes);
+  }
+#pragma unroll 1
+  for (int t = lane; t < nt; t += 64) {
+    const int code = tl[255 - t];
+    stance_leg_task<SP>(*QC_PARAMS_HERE(Pg), in, out, sout, code >> 2, code & 3, Rplanes);
+  }
+}
+
 // store the robots parked in the output stock: one per lane, or one per lane group when there are few
 template <int G, bool KIN, bool STR, int SP>
 QC_DEV void flush_out(const DevParams* __restrict__ Pg, const BatchIn& in, const BatchOut& out, const double* __restrict__ sout, int out_n, int lane,
@@ -585,6 +658,9 @@ QC_DEV void flush_out(const DevParams* __restrict__ Pg, const BatchIn& in, const
   } else if (lane < out_n) {
     CParams& P = *QC_PARAMS_HERE(Pg);
     store_from_stock<KIN, 4, SP>(P, in, out, sout, lane, 0, Rplanes ? Rplanes + lane : nullptr);
+  }
+  if constexpr (KIN) {
+    if (out.joint_tau) torque_pass<SP>(Pg, in, out, sout, out_n, lane, Rplanes);
   }
 }
 
@@ -811,12 +887,14 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
         const uint32_t sw = ia.stance ? *reinterpret_cast<const uint32_t*>(ia.stance + 4 * robot) : 0u;
         const uint32_t wv = wp ? wp[robot] : 0u;
         RawState S;
+        TickExtra X;
         double fp[12];
+        fetch_extra<KIN>(ia, robot, X);
         fetch_state<4, KIN>(ia, robot, 0, S, fp);
         asm volatile("" ::: "memory");  // (the loads above stay above)
         CParams& P = *QC_PARAMS_HERE(Pg);
         Wrench<4> W;
-        const uint32_t st = assemble_from_state<KIN, 4, false>(P, ia, robot, 0, S, fp, sw, W);
+        const uint32_t st = assemble_from_state<KIN, 4, false>(P, ia, robot, 0, S, fp, sw, X, W);
 #pragma unroll
         for (int k = 0; k < 9; k++) sin[k * SP + lane] = S.R[k];
         L.load_direct(W, st, wv, robot, 0);
@@ -1106,12 +1184,14 @@ __global__ __launch_bounds__(128, 2) void balance_pair_kernel(const DevParams* _
       const uint32_t sw = in.stance ? *reinterpret_cast<const uint32_t*>(in.stance + 4 * robot) : 0u;
       const uint32_t wv = warm ? warm[robot] : 0u;
       RawState S;
+      TickExtra X;
       double fp[12];
+      fetch_extra<KIN>(in, robot, X);
       fetch_state<4, KIN>(in, robot, 0, S, fp);
       asm volatile("" ::: "memory");  // (every load of the fill is issued above this line)
       CParams& P = *QC_PARAMS_HERE(Pg);
       Wrench<4> W;
-      const uint32_t st = assemble_from_state<KIN, 4, false>(P, in, robot, 0, S, fp, sw, W);
+      const uint32_t st = assemble_from_state<KIN, 4, false>(P, in, robot, 0, S, fp, sw, X, W);
 #pragma unroll
       for (int k = 0; k < 9; k++) lds.Rrows[9 * slot + k] = S.R[k];
       L.load_direct(W, st, wv, robot, 0);
@@ -1667,6 +1747,7 @@ int qc_set_kinematics(qc_handle* h, const qc_kinematics* kin) {
   if (!(k.tau_min <= k.tau_max)) return fail(QC_ERR_INVALID, "qc_set_kinematics: need tau_min <= tau_max");
   std::memcpy(h->dp.hip, k.hip, sizeof(k.hip));
   std::memcpy(h->dp.links, k.links, sizeof(k.links));
+  for (int l = 0; l < 4; l++) h->dp.ik_inv_2l2l3[l] = 1.0 / (2.0 * std::fabs(k.links[3 * l + 1]) * std::fabs(k.links[3 * l + 2]));
   h->dp.tau_min = k.tau_min;
   h->dp.tau_max = k.tau_max;
   std::memcpy(h->dp.jc_kff, k.jc_kff, sizeof(k.jc_kff));
@@ -1769,6 +1850,7 @@ int qc_create(const qc_params* p, int device, qc_handle** out) {
     qc_default_kinematics(&k);
     std::memcpy(d.hip, k.hip, sizeof(k.hip));
     std::memcpy(d.links, k.links, sizeof(k.links));
+    for (int l = 0; l < 4; l++) d.ik_inv_2l2l3[l] = 1.0 / (2.0 * std::fabs(k.links[3 * l + 1]) * std::fabs(k.links[3 * l + 2]));
     d.tau_min = k.tau_min;
     d.tau_max = k.tau_max;
     std::memcpy(d.jc_kff, k.jc_kff, sizeof(k.jc_kff));

@@ -61,6 +61,7 @@ struct DevParams {
   // kinematic model (joint_q / joint_tau extension): kinematics.cpp:20-47, commander_node.cpp:324-325
   double hip[12];      // [leg][xyz] base -> hip
   double links[12];    // [leg][l1,l2,l3] signed
+  double ik_inv_2l2l3[4];  // 1 / (2 |l2| |l3|) per leg (legInverseKinematics, kinematics.cpp:131)
   double tau_min, tau_max;
   double jc_kff[3], jc_kp[3], jc_kd[3];  // swing-leg joint PD (joint_controller.cpp)
   // swing reference generator (foot_planner.cpp, trajectory.cpp)
@@ -420,6 +421,35 @@ QC_DEV void leg_jt_force(CParams& P, int leg, const LegTrig& t, const double (&f
   tau[2] = j02 * f[0] + j12 * f[1] + j22 * f[2];
 }
 
+// The constants of one leg by a PER-LANE leg number (the torque pass of the joint_tau kernels gives every lane its own
+// (robot, leg) task): vector loads from the constant buffer, a handful of L1 / L2 hits per task.
+struct LegGeom {
+  double L1, L2, L3;  // signed link lengths, kinematics.cpp:20-47
+  double hx, hy, hz;  // base -> hip
+  double inv_2l2l3;   // 1 / (2 |l2| |l3|): the denominator of the knee cosine in legInverseKinematics
+};
+QC_DEV LegGeom leg_geom(CParams& P, int leg) {
+  const double* lk = (const double*)(unsigned long long)(&P.links[0]) + 3 * leg;
+  const double* hp = (const double*)(unsigned long long)(&P.hip[0]) + 3 * leg;
+  const double* iv = (const double*)(unsigned long long)(&P.ik_inv_2l2l3[0]) + leg;
+  LegGeom g;
+  g.L1 = lk[0]; g.L2 = lk[1]; g.L3 = lk[2];
+  g.hx = hp[0]; g.hy = hp[1]; g.hz = hp[2];
+  g.inv_2l2l3 = iv[0];
+  return g;
+}
+// tau = J^T f, as leg_jt_force above, for a per-lane leg
+QC_DEV void leg_jt_force(const LegGeom& g, const LegTrig& t, const double (&f)[3], double (&tau)[3]) {
+  const double a = g.L2 * t.c2 + g.L3 * t.c23;  // jac(0,1)
+  const double b = g.L2 * t.s2 + g.L3 * t.s23;
+  const double j01 = a, j02 = g.L3 * t.c23;
+  const double j10 = -g.L1 * t.s1 - a * t.c1, j11 = b * t.s1, j12 = g.L3 * t.s1 * t.s23;
+  const double j20 = g.L1 * t.c1 - a * t.s1, j21 = -b * t.c1, j22 = -g.L3 * t.s23 * t.c1;
+  tau[0] = j10 * f[1] + j20 * f[2];  // jac(0,0) = 0
+  tau[1] = j01 * f[0] + j11 * f[1] + j21 * f[2];
+  tau[2] = j02 * f[0] + j12 * f[1] + j22 * f[2];
+}
+
 // math/numerics.cpp:23-50
 QC_DEV double normalize_angle_2PI(double angle) {
   const double two_pi = 2.0 * 3.14159265358979323846;
@@ -500,26 +530,29 @@ QC_DEV void pinv3_apply(const double (&J)[9], const double (&v)[3], double (&x)[
   }
 }
 
-// Swing-leg torque of one leg, commander_node.cpp:482-504 + joint_controller.cpp:21-39.
-// pb, vb: desired foot position / velocity in the frame the reference hands to IK.
-QC_DEV void leg_swing_torque(CParams& P, int leg, const double (&pb)[3], const double (&vb)[3], const double* __restrict__ q,
-                             const double* __restrict__ qdot, double (&tau)[3]) {
-  // legInverseKinematics, kinematics.cpp:117-160 (unsigned link lengths; right legs have links[0] < 0)
-  const double l1 = fabs(P.links[3 * leg]), l2 = fabs(P.links[3 * leg + 1]), l3 = fabs(P.links[3 * leg + 2]);
-  const bool right = P.links[3 * leg] < 0.0;
-  const double x = pb[0] - P.hip[3 * leg], y = pb[1] - P.hip[3 * leg + 1], z = pb[2] - P.hip[3 * leg + 2];
-  double d = (x * x + y * y + z * z - l1 * l1 - l2 * l2 - l3 * l3) / (2.0 * l2 * l3);
-  if (d > 1.0) d = 1.0;
-  double sc = y * y + z * z - l1 * l1;
-  if (sc < 0.0) sc = 0.0;
-  const double rt = sqrt(sc);
-  double qr[3];
-  qr[0] = right ? atan2(z, y) + atan2(rt, -l1) : -(atan2(z, -y) + atan2(rt, -l1));
-  qr[2] = atan2(-sqrt(1.0 - d * d), d);
-  qr[1] = -atan2(x, rt) - atan2(l3 * sin(qr[2]), l2 + l3 * cos(qr[2]));
-  // legJacobianInverse(q_ref) * vb, kinematics.cpp:190-204 (arma::inv as the closed-form inverse; arma::pinv if singular)
-  const LegTrig t = leg_trig(qr);
-  const double L1 = P.links[3 * leg], L2 = P.links[3 * leg + 1], L3 = P.links[3 * leg + 2];
+// The same wraps with the quotient taken by a multiplication (the division is ~35 instructions, nine of them per swing leg).
+// floor() of the two quotients can differ only when the angle sits within an ulp of a multiple of 2 pi, and there both
+// versions land within an ulp of the same end of [0, 2 pi] - the subtraction and the `< 0` fix-up are the reference's.
+QC_DEV double wrap_2PI(double angle) {
+  const double two_pi = 2.0 * 3.14159265358979323846, inv = 1.0 / two_pi;
+  angle = __builtin_fma(-floor(angle * inv), two_pi, angle);
+  return angle < 0.0 ? angle + two_pi : angle;
+}
+QC_DEV double wrap_PI(double rad) {
+  const double pi = 3.14159265358979323846, two_pi = 2.0 * pi, inv = 1.0 / two_pi;
+  const double s = rad + pi;
+  double r = __builtin_fma(-floor(s * inv), two_pi, s);
+  r = r < 0.0 ? r + two_pi : r;
+  return r - pi;
+}
+
+// legJacobianInverse(q_ref) * vb (kinematics.cpp:190-204: arma::inv as the closed-form inverse; arma::pinv if singular) and
+// JointController::control (joint_controller.cpp:28-36), from the reference angles `qr` and the sines / cosines of
+// (q1, q2, q2 + q3) at q_ref.  WRAP = the wrap functions (the reference's or the multiplication form).
+template <bool FAST>
+QC_DEV void swing_pd(CParams& P, const LegGeom& g, const LegTrig& t, const double (&qr)[3], const double (&vb)[3], const double* __restrict__ q,
+                     const double* __restrict__ qdot, double (&tau)[3]) {
+  const double L1 = g.L1, L2 = g.L2, L3 = g.L3;
   const double a = L2 * t.c2 + L3 * t.c23, b = L2 * t.s2 + L3 * t.s23;
   const double J[9] = {0.0, a, L3 * t.c23, -L1 * t.s1 - a * t.c1, b * t.s1, L3 * t.s1 * t.s23, L1 * t.c1 - a * t.s1, -b * t.c1, -L3 * t.s23 * t.c1};
   const double c00 = J[4] * J[8] - J[5] * J[7], c01 = J[5] * J[6] - J[3] * J[8], c02 = J[3] * J[7] - J[4] * J[6];
@@ -531,7 +564,7 @@ QC_DEV void leg_swing_torque(CParams& P, int leg, const double (&pb)[3], const d
   const double lsum = fabs(L1) + fabs(L2) + fabs(L3);
   double qd[3];
   if (fabs(det) > 1.0e-9 * lsum * lsum * lsum) {
-    const double id = 1.0 / det;
+    const double id = FAST ? rcp_nr(det) : 1.0 / det;
     // inverse = adj / det; row r of the inverse dotted with vb
     qd[0] = id * (c00 * vb[0] + (J[2] * J[7] - J[1] * J[8]) * vb[1] + (J[1] * J[5] - J[2] * J[4]) * vb[2]);
     qd[1] = id * (c01 * vb[0] + (J[0] * J[8] - J[2] * J[6]) * vb[1] + (J[2] * J[3] - J[0] * J[5]) * vb[2]);
@@ -539,24 +572,88 @@ QC_DEV void leg_swing_torque(CParams& P, int leg, const double (&pb)[3], const d
   } else {
     pinv3_apply(J, vb, qd);
   }
-  // JointController::control, joint_controller.cpp:28-36
 #pragma unroll
   for (int c = 0; c < 3; c++) {
-    const double e = normalize_angle_PI(normalize_angle_2PI(qr[c]) - normalize_angle_2PI(q[c]));
+    const double e = FAST ? wrap_PI(wrap_2PI(qr[c]) - wrap_2PI(q[c])) : normalize_angle_PI(normalize_angle_2PI(qr[c]) - normalize_angle_2PI(q[c]));
     tau[c] = P.jc_kp[c] * e + P.jc_kd[c] * (qd[c] - qdot[c]) + P.jc_kff[c];
   }
 }
 
+// Swing-leg torque of one leg, commander_node.cpp:482-504 + joint_controller.cpp:21-39.
+// pb, vb: desired foot position / velocity in the frame the reference hands to IK.
+//
+// legInverseKinematics (kinematics.cpp:117-160) writes every reference angle as a sum of atan2's of lengths it has just
+// computed, and legJacobianInverse then takes sines and cosines of exactly those angles.  So the Jacobian at q_ref needs NO
+// trigonometry: with A = atan2(z, +-y), B = atan2(rt, -l1), C = atan2(x, rt), D = atan2(l3 s3, l2 + l3 c3),
+//   q1 = +-(A + B),  q2 = -(C + D),  q3 = atan2(-sqrt(1 - d^2), d):   sin q3 = -sqrt(1 - d^2), cos q3 = d  (unit hypotenuse),
+// the sine and cosine of each atan2(v, u) are v / hypot and u / hypot - four rsqrt's - and the sums follow from the angle-addition
+// formulas.  The three angles themselves are needed only for the PD error, which the reference wraps into [-pi, pi): one atan2
+// each of the (sin, cos) pairs gives them modulo 2 pi, which is all the wraps see.  Round 3 evaluated the chain literally:
+// five atan2, the device library's sin / cos (with its Payne-Hanek reduction) and three more sincos - ~1500 instructions per
+// swing leg against ~650.  Inputs the shortcuts do not cover - a non-finite target (atan2 has its own rules for infinities), a
+// foot exactly on the hip axes - take the reference-shaped evaluation below, so the NaN pattern of the torques stays the
+// reference's (tests/test_gpu_properties.py::test_non_finite_*).
+QC_DEV void leg_swing_torque(CParams& P, const LegGeom& g, const double (&pb)[3], const double (&vb)[3], const double* __restrict__ q,
+                             const double* __restrict__ qdot, double (&tau)[3]) {
+  // legInverseKinematics, kinematics.cpp:117-160 (unsigned link lengths; right legs have links[0] < 0)
+  const double l1 = fabs(g.L1), l2 = fabs(g.L2), l3 = fabs(g.L3);
+  const bool right = g.L1 < 0.0;
+  const double x = pb[0] - g.hx, y = pb[1] - g.hy, z = pb[2] - g.hz;
+  const double num = x * x + y * y + z * z - l1 * l1 - l2 * l2 - l3 * l3;
+  double sc = y * y + z * z - l1 * l1;
+  if (sc < 0.0) sc = 0.0;
+  const double rho2 = y * y + z * z;
+  const double rt2 = sc;  // rt^2
+  const double sig2 = x * x + rt2;
+  const bool finite = (__builtin_fma(x, 0.0, __builtin_fma(y, 0.0, z * 0.0)) == 0.0);
+  if (finite && rho2 > 0.0 && sig2 > 0.0) {
+    double d = num * g.inv_2l2l3;
+    if (d > 1.0) d = 1.0;
+    const double u = __builtin_fma(-d, d, 1.0);  // 1 - d^2 (d < -1: negative, the reference's sqrt gives NaN too)
+    const double s3 = u == 0.0 ? -0.0 : -(u * rsqrt_nr(u)), c3 = d;
+    const double rt = rt2 == 0.0 ? 0.0 : rt2 * rsqrt_nr(rt2);
+    const double ir = rsqrt_nr(rho2);                 // 1 / |(y, z)|
+    const double ib = rsqrt_nr(rt2 + l1 * l1);        // 1 / hypot(rt, l1)
+    const double is = rsqrt_nr(sig2);                 // 1 / hypot(x, rt)
+    const double kx = __builtin_fma(l3, c3, l2), ky = l3 * s3;
+    const double k2 = kx * kx + ky * ky;
+    const double ik = rsqrt_nr(k2);                   // 1 / hypot(l3 s3, l2 + l3 c3)  (k2 = 0 only for l2 = l3, d = -1)
+    const double cA = (right ? y : -y) * ir, sA = z * ir;
+    const double cB = -l1 * ib, sB = rt * ib;
+    const double sAB = sA * cB + cA * sB, cAB = cA * cB - sA * sB;
+    const double cC = rt * is, sC = x * is;
+    const double cD = k2 > 0.0 ? kx * ik : 1.0, sD = k2 > 0.0 ? ky * ik : 0.0;
+    const double sCD = sC * cD + cC * sD, cCD = cC * cD - sC * sD;
+    LegTrig t;
+    t.s1 = right ? sAB : -sAB; t.c1 = cAB;
+    t.s2 = -sCD; t.c2 = cCD;
+    t.s23 = t.s2 * c3 + t.c2 * s3;
+    t.c23 = t.c2 * c3 - t.s2 * s3;
+    const double qr[3] = {atan2(t.s1, t.c1), atan2(t.s2, t.c2), atan2(s3, c3)};
+    swing_pd<true>(P, g, t, qr, vb, q, qdot, tau);
+    return;
+  }
+  // reference-shaped evaluation (rare, divergent)
+  double d = num / (2.0 * l2 * l3);
+  if (d > 1.0) d = 1.0;
+  const double rt = sqrt(sc);
+  double qr[3], s3, c3;
+  qr[0] = right ? atan2(z, y) + atan2(rt, -l1) : -(atan2(z, -y) + atan2(rt, -l1));
+  qr[2] = atan2(-sqrt(1.0 - d * d), d);
+  sincos_joint(qr[2], &s3, &c3);  // (|q3| <= pi; NaN for a non-finite q3, as sin / cos)
+  qr[1] = -atan2(x, rt) - atan2(l3 * s3, l2 + l3 * c3);
+  swing_pd<false>(P, g, leg_trig(qr), qr, vb, q, qdot, tau);
+}
+
 // ---- swing reference generator ----------------------------------------------
 // FootPlanner::singleFoot, foot_planner.cpp:76-104 (world-frame foothold of one leg)
+// `pc` = Rwb foot_body (foot_planner.cpp:86): the lever arm r_i the wrench assembly has already computed
 QC_DEV void plan_foothold(CParams& P, int leg, const double (&R)[9], const double (&x)[3], const double (&xdot)[3], const double (&w)[3],
-                          const double (&xdot_d)[3], const double (&foot_b)[3], double (&fh)[3]) {
-  double pt[3], pc[3];
+                          const double (&xdot_d)[3], const double (&pc)[3], double (&fh)[3]) {
+  double pt[3];
 #pragma unroll
-  for (int r = 0; r < 3; r++) {
+  for (int r = 0; r < 3; r++)
     pt[r] = R[3 * r] * P.planner_hip[3 * leg] + R[3 * r + 1] * P.planner_hip[3 * leg + 1] + R[3 * r + 2] * P.planner_hip[3 * leg + 2] + x[r];
-    pc[r] = R[3 * r] * foot_b[0] + R[3 * r + 1] * foot_b[1] + R[3 * r + 2] * foot_b[2];
-  }
   const double tv[3] = {w[1] * pc[2] - w[2] * pc[1], w[2] * pc[0] - w[0] * pc[2], w[0] * pc[1] - w[1] * pc[0]};
   const double half = 0.5 * P.t_stance, lip = 0.5 * sqrt(x[2] / 9.81);
 #pragma unroll
@@ -612,6 +709,29 @@ QC_DEV void fetch_state(const BatchIn& in, long idx, int foot0, RawState& S, dou
   const double* q = (KIN ? in.joint_q : in.feet) + 12 * idx + 3 * foot0;
 #pragma unroll
   for (int k = 0; k < 3 * FPL; k++) fp[k] = q[k];
+}
+// What the widened tick reads besides the state: gait phases / duty / clock step (contact rule, gait.cpp) and the words of the
+// swing-planning record (foot_planner.cpp state_map_, trajectory.cpp traj_map_) - fetched WITH the state, not behind it.
+struct TickExtra {
+  double ph[4], duty, dt;
+  int leg_state[4], has[4];
+};
+template <bool KIN>
+QC_DEV void fetch_extra(const BatchIn& in, long robot, TickExtra& X) {
+  if (!in.stance && in.gait_phase) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) X.ph[i] = in.gait_phase[4 * robot + i];
+    if (in.gait_duty) X.duty = in.gait_duty[robot];
+    if (in.gait_dt) X.dt = in.gait_dt[robot];
+  }
+  if (KIN && in.swing_state) {
+    const SwingState* S = in.swing_state + robot;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      X.leg_state[i] = S->leg_state[i];
+      X.has[i] = S->has_traj[i];
+    }
+  }
 }
 // `foot0` = first foot owned by this lane; KIN: foot positions from joint_q by
 // forward kinematics instead of the `feet` array.  Returns 0.0 iff every input was finite.
