@@ -461,14 +461,21 @@ QC_DEV void assemble_to_stock(CParams& P, const BatchIn& in, const uint32_t* __r
 // torque pass's, below.)
 // `Rl` != nullptr: the robot's Rwb is parked in LDS (entry k at Rl[k * rstride]) by the wave's assembly phase - the one-lane
 // one-fill kernel keeps it there instead of reading the 72-byte row from global memory a second time.
-template <bool KIN, int FPL>
+// (RLDS is a template parameter, not a null test on `Rl`: a load through a pointer selected between LDS and global memory is
+// a FLAT load - it was one, nine times per robot, in every one-lane kernel of rounds 2 and 3.)
+template <bool KIN, int FPL, bool RLDS = false>
 QC_DEV void store_result(CParams& P, const BatchIn& in, const BatchOut& out, long idx, uint32_t stance, int status, int iters, uint32_t word,
                          const double (&fw)[3 * FPL], int member, const double* __restrict__ Rl = nullptr, int rstride = 0) {
   const int foot0 = member * FPL;
-  const double* Rp = in.Rwb + 9 * idx;
   double R[9];
+  if constexpr (RLDS) {
 #pragma unroll
-  for (int k = 0; k < 9; k++) R[k] = Rl ? Rl[k * rstride] : Rp[k];
+    for (int k = 0; k < 9; k++) R[k] = Rl[k * rstride];
+  } else {
+    const double* Rp = in.Rwb + 9 * idx;
+#pragma unroll
+    for (int k = 0; k < 9; k++) R[k] = Rp[k];
+  }
   const int st_out = (stance & 0x100u) ? (int)QC_NOT_PD : status;
   double* o = out.grf_body + 12 * idx + 3 * foot0;
 #pragma unroll
@@ -490,7 +497,7 @@ QC_DEV void store_result(CParams& P, const BatchIn& in, const BatchOut& out, lon
   }
 }
 
-template <bool KIN, int FPL, int SP>
+template <bool KIN, int FPL, int SP, bool RLDS = false>
 QC_DEV void store_from_stock(CParams& P, const BatchIn& in, const BatchOut& out, const double* __restrict__ sout, int slot, int member,
                              const double* __restrict__ Rl = nullptr) {
   const int foot0 = member * FPL;
@@ -500,7 +507,7 @@ QC_DEV void store_from_stock(CParams& P, const BatchIn& in, const BatchOut& out,
   double fw[3 * FPL];
 #pragma unroll
   for (int k = 0; k < 3 * FPL; k++) fw[k] = sout[(OUT_F + 3 * foot0 + k) * SP + slot];
-  store_result<KIN, FPL>(P, in, out, idx, (uint32_t)(ww >> 32), (int)(uint32_t)sw, (int)(uint32_t)(sw >> 32), (uint32_t)ww, fw, member, Rl, SP);
+  store_result<KIN, FPL, RLDS>(P, in, out, idx, (uint32_t)(ww >> 32), (int)(uint32_t)sw, (int)(uint32_t)(sw >> 32), (uint32_t)ww, fw, member, Rl, SP);
 }
 
 // dense assembly of the next (up to 64) robots of the chunk into the input stock; returns how many
@@ -533,20 +540,11 @@ QC_DEV int restock(const DevParams* __restrict__ Pg, const BatchIn& in, const ui
 // The lists (one byte per task: slot << 2 | leg; swing tasks from the front, stance tasks from the back of a 256-byte array
 // behind the stock planes) are built with ballots and mbcnt, leg-major, so neighbouring lanes still touch neighbouring robots.
 
-// the robot in `slot` of the output stock: index, stance word, status as store_result reports it, Rwb (from the wave's LDS
-// rows when the assembly parked it there)
-template <int SP>
-QC_DEV void task_robot(const BatchIn& in, const double* __restrict__ sout, int slot, const double* __restrict__ Rplanes, long& idx, uint32_t& stance,
-                       int& st_out, double (&R)[9]) {
-  idx = __double_as_longlong(sout[OUT_IDX * SP + slot]);
-  const unsigned long long sw = (unsigned long long)__double_as_longlong(sout[OUT_STAT * SP + slot]);
-  const unsigned long long ww = (unsigned long long)__double_as_longlong(sout[OUT_WORD * SP + slot]);
-  stance = (uint32_t)(ww >> 32);
-  st_out = (stance & 0x100u) ? (int)QC_NOT_PD : (int)(uint32_t)sw;
-  const double* Rp = in.Rwb + 9 * idx;
-#pragma unroll
-  for (int k = 0; k < 9; k++) R[k] = Rplanes ? Rplanes[k * SP + slot] : Rp[k];
-}
+// What makes the pass cheap is mostly WHEN its loads are issued (a wave of a one-round launch has its SIMD to itself: a
+// dependent global load is ~1 us of nothing): the stance legs' joint angles are requested before the force stores, the first
+// swing pass's inputs before the stance legs are computed, and every further swing pass's inputs while the previous one computes.
+// So the cheap stance map (J^T f: three sincos and a dozen products per leg) stays one robot per lane - its loads are one
+// coalesced batch and its per-leg constants scalar - and only the swing chain (IK, J^-1, PD: ~650 instructions) is compacted.
 QC_DEV void store_tau(CParams& P, const BatchOut& out, long idx, int leg, const double (&tau)[3], bool emit) {
   double* to = out.joint_tau + 12 * idx + 3 * leg;
 #pragma unroll
@@ -557,98 +555,187 @@ QC_DEV void store_tau(CParams& P, const BatchOut& out, long idx, int leg, const 
     to[r] = emit ? (t < P.tau_min ? P.tau_min : (t > P.tau_max ? P.tau_max : t)) : 0.0;
   }
 }
-// stance leg (or a swing leg of a batch without swing references: zero torque): tau = clamp(J^T f_body), kinematics.cpp:219-231
-template <int SP>
-QC_DEV void stance_leg_task(CParams& P, const BatchIn& in, const BatchOut& out, const double* __restrict__ sout, int slot, int leg,
-                            const double* __restrict__ Rplanes) {
-  long idx; uint32_t stance; int st_out; double R[9];
-  task_robot<SP>(in, sout, slot, Rplanes, idx, stance, st_out, R);
-  const bool st = ((stance >> leg) & 1u) && st_out == QC_SOLVED;
-  double f[3], fb[3], tau[3];
-#pragma unroll
-  for (int k = 0; k < 3; k++) f[k] = sout[(OUT_F + 3 * leg + k) * SP + slot];
-#pragma unroll
-  for (int r = 0; r < 3; r++) fb[r] = st ? -(R[r] * f[0] + R[3 + r] * f[1] + R[6 + r] * f[2]) : 0.0;  // BC.cpp:218-232
-  const LegGeom g = leg_geom(P, leg);
-  leg_jt_force(g, leg_trig(in.joint_q + 12 * idx + 3 * leg), fb, tau);
-  store_tau(P, out, idx, leg, tau, st);
-}
-// swing leg: reference foot state -> IK -> J^-1 -> joint PD, commander_node.cpp:482-504; independent of the QP's status
-template <int SP>
-QC_DEV void swing_leg_task(CParams& P, const BatchIn& in, const BatchOut& out, const double* __restrict__ sout, int slot, int leg,
-                           const double* __restrict__ Rplanes) {
-  long idx; uint32_t stance; int st_out; double R[9];
-  task_robot<SP>(in, sout, slot, Rplanes, idx, stance, st_out, R);
-  double sp[3], sv[3];
+// what one swing-leg task reads from memory
+struct SwingIn {
+  long idx;
+  int leg, has;
+  double q[3], qdot[3], x[3], a[3], b[3], ph;  // a, b: trajectory end points (swing_state) or reference position / velocity (swing_pos / swing_vel)
+};
+QC_DEV void swing_fetch(const BatchIn& in, long idx, int leg, SwingIn& T) {
+  T.idx = idx;
+  T.leg = leg;
+  T.has = 1;
+  T.ph = 0.0;
   if (in.swing_state) {  // FootTrajectoryManager::referenceState(leg, phase), trajectory.cpp:360-388
     const SwingState* S = in.swing_state + idx;
     // written by this wave's assembly phase: read past the (possibly stale) vector L1
-    const int has = __hip_atomic_load(&S->has_traj[leg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    double p0[3], pf[3];
+    T.has = __hip_atomic_load(&S->has_traj[leg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
     for (int r = 0; r < 3; r++) {
-      p0[r] = __hip_atomic_load(&S->p_start[3 * leg + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      pf[r] = __hip_atomic_load(&S->p_final[3 * leg + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      T.a[r] = __hip_atomic_load(&S->p_start[3 * leg + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      T.b[r] = __hip_atomic_load(&S->p_final[3 * leg + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    const double ph = in.gait_dt ? __hip_atomic_load(in.gait_phase + 4 * idx + leg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                 : in.gait_phase[4 * idx + leg];
-    track_swing(P, ph, p0, pf, sp, sv);
-    if (!has) sp[0] = sp[1] = sp[2] = sv[0] = sv[1] = sv[2] = 0.0;  // no trajectory: FootState() (:387)
+    T.ph = in.gait_dt ? __hip_atomic_load(in.gait_phase + 4 * idx + leg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : in.gait_phase[4 * idx + leg];
   } else {
 #pragma unroll
     for (int r = 0; r < 3; r++) {
-      sp[r] = in.swing_pos[12 * idx + 3 * leg + r];
-      sv[r] = in.swing_vel[12 * idx + 3 * leg + r];
+      T.a[r] = in.swing_pos[12 * idx + 3 * leg + r];
+      T.b[r] = in.swing_vel[12 * idx + 3 * leg + r];
     }
   }
-  const double* xp = in.x + 3 * idx;
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    T.q[r] = in.joint_q[12 * idx + 3 * leg + r];
+    T.qdot[r] = in.joint_qdot[12 * idx + 3 * leg + r];
+    T.x[r] = in.x[3 * idx + r];
+  }
+}
+// swing leg: reference foot state -> IK -> J^-1 -> joint PD, commander_node.cpp:482-504; independent of the QP's status
+QC_DEV void swing_leg_task(CParams& P, const BatchIn& in, const BatchOut& out, const SwingIn& T, const double (&R)[9]) {
+  double sp[3], sv[3];
+  if (in.swing_state) {
+    track_swing(P, T.ph, T.a, T.b, sp, sv);
+    if (!T.has) sp[0] = sp[1] = sp[2] = sv[0] = sv[1] = sv[2] = 0.0;  // no trajectory: FootState() (:387)
+  } else {
+#pragma unroll
+    for (int r = 0; r < 3; r++) { sp[r] = T.a[r]; sv[r] = T.b[r]; }
+  }
   double pb[3], vb[3], tau[3];
 #pragma unroll
   for (int r = 0; r < 3; r++) {
-    pb[r] = R[r] * sp[0] + R[3 + r] * sp[1] + R[6 + r] * sp[2] - xp[r];  // Rwb^T pos - x (sic, :492)
+    pb[r] = R[r] * sp[0] + R[3 + r] * sp[1] + R[6 + r] * sp[2] - T.x[r];  // Rwb^T pos - x (sic, :492)
     vb[r] = R[r] * sv[0] + R[3 + r] * sv[1] + R[6 + r] * sv[2];          // Rwb^T vel (:493)
   }
-  const LegGeom g = leg_geom(P, leg);
-  leg_swing_torque(P, g, pb, vb, in.joint_q + 12 * idx + 3 * leg, in.joint_qdot + 12 * idx + 3 * leg, tau);
-  store_tau(P, out, idx, leg, tau, true);
+  const LegGeom g = leg_geom(P, T.leg);
+  leg_swing_torque(P, g, pb, vb, T.q, T.qdot, tau);
+  store_tau(P, out, T.idx, T.leg, tau, true);
 }
-template <int SP>
-QC_DEV void torque_pass(const DevParams* __restrict__ Pg, const BatchIn& in, const BatchOut& out, const double* __restrict__ sout, int out_n, int lane,
-                        const double* __restrict__ Rplanes) {
-  unsigned char* const tl = reinterpret_cast<unsigned char*>(const_cast<double*>(sout) + OUT_PLANES * SP);  // (TASK_DOUBLES behind the planes)
-  const bool have_swing = in.swing_pos || in.swing_state;
-  const bool mine = lane < out_n;
-  uint32_t stance = 0xFu;
-  if (mine) stance = (uint32_t)((unsigned long long)__double_as_longlong(sout[OUT_WORD * SP + lane]) >> 32);
-  int ns = 0, nt = 0;
+// Rwb of the robot in `slot`: the wave's LDS rows (RLDS: the one-lane one-fill kernel parked it there) or global memory
+template <int SP, bool RLDS>
+QC_DEV void task_rwb(const BatchIn& in, const double* __restrict__ Rplanes, int slot, long idx, double (&R)[9]) {
+  if constexpr (RLDS) {
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const bool sw = mine && have_swing && !((stance >> i) & 1u);
-    const bool st = mine && !sw;
-    const unsigned long long ms = __builtin_amdgcn_ballot_w64(sw), mt = __builtin_amdgcn_ballot_w64(st);
-    const unsigned char code = (unsigned char)((lane << 2) | i);
-    if (sw) tl[ns + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(ms >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ms, 0))] = code;
-    if (st) tl[255 - nt - (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mt >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mt, 0))] = code;
-    ns += __builtin_popcountll(ms);
-    nt += __builtin_popcountll(mt);
-  }
-  __syncthreads();
-#pragma unroll 1
-  for (int t = lane; t < ns; t += 64) {
-    const int code = tl[t];
-    swing_leg_task<SP>(*QC_PARAMS_HERE(Pg), in, out, sout, code >> 2, code & 3, Rplanes);
-  }
-#pragma unroll 1
-  for (int t = lane; t < nt; t += 64) {
-    const int code = tl[255 - t];
-    stance_leg_task<SP>(*QC_PARAMS_HERE(Pg), in, out, sout, code >> 2, code & 3, Rplanes);
+    for (int k = 0; k < 9; k++) R[k] = Rplanes[k * SP + slot];
+  } else {
+    const double* Rp = in.Rwb + 9 * idx;
+#pragma unroll
+    for (int k = 0; k < 9; k++) R[k] = Rp[k];
   }
 }
 
+// joint angles of this lane's robot, requested before anything else in the flush (consumed by torque_pass)
+struct TorquePre {
+  double q[12];
+};
+template <int SP>
+QC_DEV void torque_prefetch(const BatchIn& in, const double* __restrict__ sout, int out_n, int lane, TorquePre& T) {
+  if (lane < out_n) {
+    const long idx = __double_as_longlong(sout[OUT_IDX * SP + lane]);
+    const double* qp = in.joint_q + 12 * idx;
+#pragma unroll
+    for (int k = 0; k < 12; k++) T.q[k] = qp[k];
+  }
+}
+template <int SP, bool RLDS>
+QC_DEV void torque_pass(const DevParams* __restrict__ Pg, const BatchIn& in, const BatchOut& out, const double* __restrict__ sout, int out_n, int lane,
+                        const double* __restrict__ Rplanes, TorquePre& Q) {
+  QC_CLK_ABS(8, 13);
+  unsigned char* const tl = reinterpret_cast<unsigned char*>(const_cast<double*>(sout) + OUT_PLANES * SP);  // (TASK_DOUBLES behind the planes)
+  const bool have_swing = in.swing_pos || in.swing_state;
+  const bool mine = lane < out_n;
+  long idx = 0;
+  uint32_t stance = 0xFu;
+  int st_out = QC_NOT_PD;
+  if (mine) {
+    idx = __double_as_longlong(sout[OUT_IDX * SP + lane]);
+    const unsigned long long sw = (unsigned long long)__double_as_longlong(sout[OUT_STAT * SP + lane]);
+    stance = (uint32_t)((unsigned long long)__double_as_longlong(sout[OUT_WORD * SP + lane]) >> 32);
+    st_out = (stance & 0x100u) ? (int)QC_NOT_PD : (int)(uint32_t)sw;
+  }
+  // the swing-leg tasks of the wave, leg-major (neighbouring lanes touch neighbouring robots): one byte each, slot << 2 | leg
+  int ns = 0;
+  if (have_swing) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const bool sw = mine && !((stance >> i) & 1u);
+      const unsigned long long ms = __builtin_amdgcn_ballot_w64(sw);
+      if (sw) tl[ns + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(ms >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ms, 0))] = (unsigned char)((lane << 2) | i);
+      ns += __builtin_popcountll(ms);
+    }
+    __syncthreads();
+  }
+  // The joint angles requested at the top of the flush have to BE here before the swing inputs are requested: vector-memory
+  // results return in order, so waiting for them later would wait for the (slower, L1-bypassing) swing loads as well.
+#pragma unroll
+  for (int k = 0; k < 12; k++) asm volatile("" : "+v"(Q.q[k]));
+  SwingIn nxt;
+  int nslot = 0;
+  if (lane < ns) {  // the first swing pass's inputs: in flight while the stance legs are computed
+    const int code = tl[lane];
+    nslot = code >> 2;
+    swing_fetch(in, __double_as_longlong(sout[OUT_IDX * SP + nslot]), code & 3, nxt);
+  }
+  asm volatile("" ::: "memory");  // (... and requested above this line, not behind the stance legs' arithmetic)
+  QC_CLK_ABS(13, 15);
+  // stance legs (and the swing legs of a batch without swing references: zero torque), one robot per lane:
+  // tau = clamp(J^T f_body), kinematics.cpp:219-231, commander_node.cpp:511-526
+  {
+    CParams& P = *QC_PARAMS_HERE(Pg);
+    double R[9];
+    if (mine) {
+      task_rwb<SP, RLDS>(in, Rplanes, lane, idx, R);
+      // Branch-free over the four legs on purpose: a wave of a one-round launch has its SIMD to itself and a leg's three
+      // sincos are serial polynomial chains - twelve of them interleaved issue back to back, one leg at a time behind a
+      // "does any lane need this leg" branch they ran at ~10 cycles per instruction (8.8 k cycles for the four legs).
+      LegTrig tr[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const double qa[3] = {Q.q[3 * i], Q.q[3 * i + 1], Q.q[3 * i + 2]};
+        tr[i] = leg_trig(qa);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const bool stl = (stance >> i) & 1u;
+        const bool todo = !(have_swing && !stl);  // (a swing leg with swing references belongs to the swing tasks below)
+        const bool st = stl && st_out == QC_SOLVED;
+        double f[3], fb[3], tau[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) f[k] = sout[(OUT_F + 3 * i + k) * SP + lane];
+#pragma unroll
+        for (int r = 0; r < 3; r++) fb[r] = st ? -(R[r] * f[0] + R[3 + r] * f[1] + R[6 + r] * f[2]) : 0.0;  // BC.cpp:218-232
+        leg_jt_force(P, i, tr[i], fb, tau);
+        if (todo) store_tau(P, out, idx, i, tau, st);
+      }
+    }
+  }
+  QC_CLK_ABS(15, 14);
+#pragma unroll 1
+  for (int t = lane; t < ns; t += 64) {
+    const SwingIn cur = nxt;
+    const int cslot = nslot;
+    if (t + 64 < ns) {  // the next pass's inputs are requested before this pass computes
+      const int code = tl[t + 64];
+      nslot = code >> 2;
+      swing_fetch(in, __double_as_longlong(sout[OUT_IDX * SP + nslot]), code & 3, nxt);
+    }
+    double R[9];
+    task_rwb<SP, RLDS>(in, Rplanes, cslot, cur.idx, R);
+    swing_leg_task(*QC_PARAMS_HERE(Pg), in, out, cur, R);
+  }
+  QC_CLK_ABS(14, 8);
+}
+
 // store the robots parked in the output stock: one per lane, or one per lane group when there are few
-template <int G, bool KIN, bool STR, int SP>
+template <int G, bool KIN, bool STR, int SP, bool RLDS = false>
 QC_DEV void flush_out(const DevParams* __restrict__ Pg, const BatchIn& in, const BatchOut& out, const double* __restrict__ sout, int out_n, int lane,
                       const double* __restrict__ Rplanes = nullptr) {
+  TorquePre tq;
+  if constexpr (KIN) {
+    if (out.joint_tau) {
+      torque_prefetch<SP>(in, sout, out_n, lane, tq);
+      asm volatile("" ::: "memory");  // (requested HERE: left alone, the compiler sinks these loads to their first use, behind the swing inputs)
+    }
+  }
   if (G > 1 && out_n <= 64 / G) {
     const int grp = lane_group<G, STR>(lane);
     if (grp < out_n) {
@@ -657,10 +744,10 @@ QC_DEV void flush_out(const DevParams* __restrict__ Pg, const BatchIn& in, const
     }
   } else if (lane < out_n) {
     CParams& P = *QC_PARAMS_HERE(Pg);
-    store_from_stock<KIN, 4, SP>(P, in, out, sout, lane, 0, Rplanes ? Rplanes + lane : nullptr);
+    store_from_stock<KIN, 4, SP, RLDS>(P, in, out, sout, lane, 0, RLDS ? Rplanes + lane : nullptr);
   }
   if constexpr (KIN) {
-    if (out.joint_tau) torque_pass<SP>(Pg, in, out, sout, out_n, lane, Rplanes);
+    if (out.joint_tau) torque_pass<SP, RLDS>(Pg, in, out, sout, out_n, lane, Rplanes, tq);
   }
 }
 
@@ -1044,7 +1131,7 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
     }
     QC_CLK(7, 8);
     __syncthreads();
-    flush_out<Eqp::G, KIN, STR, SP>(Pg, in, out, sout, stock_n, lane, DIRECT ? sin : nullptr);
+    flush_out<Eqp::G, KIN, STR, SP, DIRECT>(Pg, in, out, sout, stock_n, lane, DIRECT ? sin : nullptr);
     QC_CLK_END(8);
     return;
   }
@@ -1210,7 +1297,7 @@ __global__ __launch_bounds__(128, 2) void balance_pair_kernel(const DevParams* _
     }
     if (mine && !busy) {
       CParams& P = *QC_PARAMS_HERE(Pg);
-      store_result<KIN, 4>(P, in, out, robot, L.stance, L.status, L.iters, L.word_bits() | 0x80000000u, L.f, 0, lds.Rrows + 9 * slot, 1);
+      store_result<KIN, 4, true>(P, in, out, robot, L.stance, L.status, L.iters, L.word_bits() | 0x80000000u, L.f, 0, lds.Rrows + 9 * slot, 1);
     }
     const int nb = __builtin_popcountll(bm);
     int first = 0;
@@ -1278,7 +1365,7 @@ __global__ __launch_bounds__(128, 2) void balance_pair_kernel(const DevParams* _
   auto push4 = [&](const Lane4& X, int rs) {  // this lane's foot of a finished robot, straight to the outputs
     const uint32_t word = (uint32_t)group_or<4, true>((int)X.word_bits()) | 0x80000000u;
     CParams& P = *QC_PARAMS_HERE(Pg);
-    store_result<KIN, 1>(P, in, out, X.idx, X.stance, X.status, X.iters, word, X.f, j4, lds.Rrows + 9 * rs, 1);
+    store_result<KIN, 1, true>(P, in, out, X.idx, X.stance, X.status, X.iters, word, X.f, j4, lds.Rrows + 9 * rs, 1);
   };
   // groups without a robot shadow ticket 0 (the strided layout keeps every lane in the loop: MFMA sums read all 64)
   bool busy4 = g4 < T;
@@ -1359,7 +1446,7 @@ __global__ __launch_bounds__(128, 2) void balance_pair_kernel(const DevParams* _
     if (r < nrun && sid == win) {
       const uint32_t word = (uint32_t)group_or<4, true>((int)LR.word_bits()) | 0x80000000u;
       CParams& P = *QC_PARAMS_HERE(Pg);
-      store_result<KIN, 1>(P, in, out, LR.idx, LR.stance, LR.status, LR.iters, word, LR.f, j4, lds.Rrows + 9 * rs, 1);
+      store_result<KIN, 1, true>(P, in, out, LR.idx, LR.stance, LR.status, LR.iters, word, LR.f, j4, lds.Rrows + 9 * rs, 1);
     }
   }
   QC_CLK_END(8);

@@ -34,6 +34,9 @@
 #define QC_CLK_TAIL_END()
 #define QC_CLK_PIN(arr)  // harness: pins the values of `arr` at this point so the scheduler cannot move a phase across its marker
 #endif
+#ifndef QC_CLK_ABS
+#define QC_CLK_ABS(from, to)  // harness: a phase boundary between two absolute clock slots (the torque pass: 13 lists, 14 swing, 15 stance)
+#endif
 
 #ifndef QC_NO_STRIDED
 #define QC_NO_STRIDED 0  // development: 1 keeps the adjacent-lane (DPP) layout in the 4-lanes-per-robot kernels

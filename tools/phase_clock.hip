@@ -5,6 +5,7 @@
 //   6 forces + gradient                 7 ratio test, multipliers, state update    8 final flush (output transform + store)
 //   9 empty (marker cost, counted twice per iterate)
 //   10 iterate calls                    11 s_memrealtime ticks (100 MHz) start -> end, 12 s_memtime ticks start -> end
+//   13 / 14 / 15: the torque pass of the widened tick (task lists, swing-leg tasks, stance-leg tasks; 8 keeps the GRF stores)
 //   16 + k: phase k of the recalculations of the 4-lane tail (one / two lanes-per-robot kernels), 26 their count; 1 = the re-pack
 // Each marker costs one s_memtime + s_waitcnt (~50-100 cycles): compare phases, do not read totals as product time.
 #include <hip/hip_runtime.h>
@@ -29,6 +30,7 @@ __shared__ int qc_clk_off;  // 0, or 16 while the 4-lane tail runs (slots 16 + p
       atomicAdd(&qc_clk_lds[to], 0ull - t_);                                           \
     }                                                                                  \
   } while (0)
+#define QC_CLK_ABS(from, to) QC_CLK_X(from, to)  /* torque pass of the widened tick: 13 task lists, 14 swing-leg tasks, 15 stance-leg tasks */
 #define QC_CLK_TAIL_BEGIN() do { QC_CLK_X(7, 1); } while (0)                 /* slot 1: the re-pack */
 #define QC_CLK_TAIL_LOOP() do { QC_CLK_X(1, 23); qc_clk_off = 16; } while (0)
 #define QC_CLK_TAIL_END() do { qc_clk_off = 0; QC_CLK_X(23, 7); } while (0)
