@@ -137,8 +137,10 @@ struct Lane {
   // tests/test_gpu_matrix.py::test_iteration_cap_and_bad_inputs_agree_across_widths holds status, iteration count and the
   // (zero) forces of capped / bad robots equal across the lane-group widths.
   enum { MIXED = 0, FIRST = 1, STEADY = 2 };
+  // `empty_set` (wave-uniform): every robot of the wave still has the EMPTY working set - the first recalculation of a cold
+  // fill.  With no active face there is no multiplier to test (every candidate is +BIG), so the test is skipped.
   template <int PHASE = MIXED, class PT>
-  QC_DEV bool iterate(const PT& P, Eqp& eqp, const bool live = true) {
+  QC_DEV bool iterate(const PT& P, Eqp& eqp, const bool live = true, const bool empty_set = false) {
     double fh[3 * FPL], g[3 * FPL];
     iters += live ? 1 : 0;
     const bool pd = eqp.solve(P, Wr, C, stance, foot0, fh, g);
@@ -200,9 +202,12 @@ struct Lane {
     }
     // multiplier test, meaningful when f landed on f^
     const bool at_fh = fresh ? !changed : !blocked;
-    int wcode;
+    int wcode = -1;
     bool neg[3 * FPL];
-    const bool opt = multipliers_ok(P, g, wcode, neg);
+#pragma unroll
+    for (int k = 0; k < 3 * FPL; k++) neg[k] = false;
+    bool opt = true;
+    if (!(PHASE == FIRST && empty_set)) opt = multipliers_ok(P, g, wcode, neg);
     if (!at_fh) wcode = -1;
     const bool dall = RACE & drop_all & at_fh;  // this lane's strategy drops every negative multiplier at once
     const bool take_clamp = fresh & changed;
@@ -1040,9 +1045,9 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
         bool done;
         if constexpr (RESIDENT) {
           pin_uconst(uc);
-          done = L.template iterate<LaneT::FIRST>(uc, eqp, busy);
+          done = L.template iterate<LaneT::FIRST>(uc, eqp, busy, k == 0 && warm == nullptr);
         } else {
-          done = L.template iterate<LaneT::FIRST>(*QC_PARAMS_HERE(Pg), eqp, busy);
+          done = L.template iterate<LaneT::FIRST>(*QC_PARAMS_HERE(Pg), eqp, busy, k == 0 && warm == nullptr);
         }
         after(done);
       }
@@ -1103,9 +1108,9 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
       if (busy) {  // every robot of a one-fill wave is fresh exactly once: the clamp steps are peeled
         if constexpr (RESIDENT) {
           pin_uconst(uc);
-          busy = !L.template iterate<LaneT::FIRST>(uc, eqp);
+          busy = !L.template iterate<LaneT::FIRST>(uc, eqp, true, k == 0 && warm == nullptr);
         } else {
-          busy = !L.template iterate<LaneT::FIRST>(*QC_PARAMS_HERE(Pg), eqp);
+          busy = !L.template iterate<LaneT::FIRST>(*QC_PARAMS_HERE(Pg), eqp, true, k == 0 && warm == nullptr);
         }
       }
     }
@@ -1289,7 +1294,7 @@ __global__ __launch_bounds__(128, 2) void balance_pair_kernel(const DevParams* _
     const int first_steps = clamp_steps_for<1>(*QC_PARAMS_HERE(Pg), warm);
 #pragma unroll 1
     for (int k = 0; k < first_steps; k++)
-      if (busy) busy = !L.template iterate<Lane1::FIRST>(*QC_PARAMS_HERE(Pg), eqp);
+      if (busy) busy = !L.template iterate<Lane1::FIRST>(*QC_PARAMS_HERE(Pg), eqp, true, k == 0 && warm == nullptr);
     unsigned long long bm = __builtin_amdgcn_ballot_w64(busy);
     while (__builtin_popcountll(bm) > th) {
       if (busy) busy = !L.template iterate<Lane1::STEADY>(*QC_PARAMS_HERE(Pg), eqp);
