@@ -638,16 +638,21 @@ void oracle_swing_torque(const oracle_kinematics* k, int leg, const double* Rwb,
   oracle_leg_jacobian(k, leg, qr, J);     /* legJacobianInverse, kinematics.cpp:190-204 */
   {
     /* legJacobianInverse, kinematics.cpp:190-204: arma::inv, if that fails arma::pinv, if that fails J^T.
-     * inv: Gauss-Jordan with partial pivoting (what LAPACK getrf+getri amounts to for a 3x3).  A singular J - leg
-     * fully stretched: the reference point is out of reach and IK clamps d to 1, so q3 = 0 and the last two
-     * columns are parallel (rank 2; rank 1 when y^2 + z^2 < l1^2 is clamped as well) - takes the pinv branch
-     * (:196).  The switch: |det| <= 1e-9 (|l1|+|l2|+|l3|)^3 or an exact zero pivot (the reference's own switch is
-     * Armadillo's "|det| < epsilon, then LAPACK info != 0"; between the two thresholds arma::inv returns a
-     * 1/sigma_3-sized inverse whose torque the clamp of commander_node.cpp:526 saturates - INTEGRATION.md). */
+     * arma::inv of a 3x3 is Armadillo's closed-form "tiny" inverse for epsilon <= |det| <= 1 / epsilon (recalled from
+     * Armadillo 10.2's op_inv, not verifiable here); outside that band it calls LAPACK, whose LU returns a 1/sigma_3-sized
+     * "inverse" unless a pivot is exactly zero, and only then arma::pinv answers (:196).  Restated here: the closed-form band
+     * is inverted (Gauss-Jordan with partial pivoting - same values as the cofactor formula to rounding), everything
+     * outside it takes the pinv branch.  A singular J - leg fully stretched: the reference point is out of reach and IK
+     * clamps d to 1, so q3 = 0 and the last two columns are parallel (|det| ~ 1e-18 of rounding noise; rank 1 when
+     * y^2 + z^2 < l1^2 is clamped as well) - therefore always gets pinv, where the reference gets pinv or a full-scale
+     * clamped torque depending on rounding inside LAPACK (tests/test_oracle_cpu.py puts numbers on it). */
     double M[3][6];
     const double det = J[0] * (J[4] * J[8] - J[5] * J[7]) + J[1] * (J[5] * J[6] - J[3] * J[8]) + J[2] * (J[3] * J[7] - J[4] * J[6]);
+    /* (lower end raised to det's own rounding noise, 64 epsilon (sum |l|)^3, where that is larger: below it the sign of
+     * det - and of the saturated torque it leads to - is noise on any implementation) */
     const double lsum = fabs(k->links[3 * leg]) + fabs(k->links[3 * leg + 1]) + fabs(k->links[3 * leg + 2]);
-    int singular = !(fabs(det) > 1.0e-9 * lsum * lsum * lsum);
+    const double det_lo = fmax(2.220446049250313e-16, 1.4210854715202004e-14 * lsum * lsum * lsum);
+    int singular = !(fabs(det) >= det_lo && fabs(det) <= 4503599627370496.0);
     for (int i = 0; i < 3; i++)
       for (int j = 0; j < 3; j++) { M[i][j] = J[3 * i + j]; M[i][3 + j] = (i == j) ? 1.0 : 0.0; }
     for (int c = 0; c < 3 && !singular; c++) {

@@ -1839,7 +1839,6 @@ int qc_set_kinematics(qc_handle* h, const qc_kinematics* kin) {
   if (!(k.tau_min <= k.tau_max)) return fail(QC_ERR_INVALID, "qc_set_kinematics: need tau_min <= tau_max");
   std::memcpy(h->dp.hip, k.hip, sizeof(k.hip));
   std::memcpy(h->dp.links, k.links, sizeof(k.links));
-  for (int l = 0; l < 4; l++) h->dp.ik_inv_2l2l3[l] = 1.0 / (2.0 * std::fabs(k.links[3 * l + 1]) * std::fabs(k.links[3 * l + 2]));
   h->dp.tau_min = k.tau_min;
   h->dp.tau_max = k.tau_max;
   std::memcpy(h->dp.jc_kff, k.jc_kff, sizeof(k.jc_kff));
@@ -1942,7 +1941,6 @@ int qc_create(const qc_params* p, int device, qc_handle** out) {
     qc_default_kinematics(&k);
     std::memcpy(d.hip, k.hip, sizeof(k.hip));
     std::memcpy(d.links, k.links, sizeof(k.links));
-    for (int l = 0; l < 4; l++) d.ik_inv_2l2l3[l] = 1.0 / (2.0 * std::fabs(k.links[3 * l + 1]) * std::fabs(k.links[3 * l + 2]));
     d.tau_min = k.tau_min;
     d.tau_max = k.tau_max;
     std::memcpy(d.jc_kff, k.jc_kff, sizeof(k.jc_kff));

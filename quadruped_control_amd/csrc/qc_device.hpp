@@ -64,7 +64,6 @@ struct DevParams {
   // kinematic model (joint_q / joint_tau extension): kinematics.cpp:20-47, commander_node.cpp:324-325
   double hip[12];      // [leg][xyz] base -> hip
   double links[12];    // [leg][l1,l2,l3] signed
-  double ik_inv_2l2l3[4];  // 1 / (2 |l2| |l3|) per leg (legInverseKinematics, kinematics.cpp:131)
   double tau_min, tau_max;
   double jc_kff[3], jc_kp[3], jc_kd[3];  // swing-leg joint PD (joint_controller.cpp)
   // swing reference generator (foot_planner.cpp, trajectory.cpp)
@@ -429,16 +428,13 @@ QC_DEV void leg_jt_force(CParams& P, int leg, const LegTrig& t, const double (&f
 struct LegGeom {
   double L1, L2, L3;  // signed link lengths, kinematics.cpp:20-47
   double hx, hy, hz;  // base -> hip
-  double inv_2l2l3;   // 1 / (2 |l2| |l3|): the denominator of the knee cosine in legInverseKinematics
 };
 QC_DEV LegGeom leg_geom(CParams& P, int leg) {
   const double* lk = (const double*)(unsigned long long)(&P.links[0]) + 3 * leg;
   const double* hp = (const double*)(unsigned long long)(&P.hip[0]) + 3 * leg;
-  const double* iv = (const double*)(unsigned long long)(&P.ik_inv_2l2l3[0]) + leg;
   LegGeom g;
   g.L1 = lk[0]; g.L2 = lk[1]; g.L3 = lk[2];
   g.hx = hp[0]; g.hy = hp[1]; g.hz = hp[2];
-  g.inv_2l2l3 = iv[0];
   return g;
 }
 // tau = J^T f, as leg_jt_force above, for a per-lane leg
@@ -560,13 +556,19 @@ QC_DEV void swing_pd(CParams& P, const LegGeom& g, const LegTrig& t, const doubl
   const double J[9] = {0.0, a, L3 * t.c23, -L1 * t.s1 - a * t.c1, b * t.s1, L3 * t.s1 * t.s23, L1 * t.c1 - a * t.s1, -b * t.c1, -L3 * t.s23 * t.c1};
   const double c00 = J[4] * J[8] - J[5] * J[7], c01 = J[5] * J[6] - J[3] * J[8], c02 = J[3] * J[7] - J[4] * J[6];
   const double det = J[0] * c00 + J[1] * c01 + J[2] * c02;
-  // A singular J - leg fully stretched because the reference point is out of reach, where IK clamps d to 1 and q3 = 0 -
-  // makes arma::inv fail in the reference and arma::pinv answer (kinematics.cpp:194-196).  The switch (the same in the
-  // checker under oracle/): |det| <= 1e-9 (|l1|+|l2|+|l3|)^3 (Armadillo's own: |det| < epsilon, then an exact zero LAPACK pivot - between the
-  // two the reference multiplies by a 1/sigma_3-sized inverse and the torque clamp saturates).
-  const double lsum = fabs(L1) + fabs(L2) + fabs(L3);
+  // arma::inv of a 3x3 (kinematics.cpp:194) is Armadillo's closed-form "tiny" inverse whenever epsilon <= |det| <= 1 / epsilon;
+  // outside that band it hands the matrix to LAPACK, whose LU succeeds - with a 1/sigma_3 ~ 1e17-sized "inverse" - unless it
+  // meets an exactly zero pivot, and only then does arma::pinv answer (:196).  This build (and the checker under oracle/) keeps
+  // the closed-form band exactly and answers the whole LAPACK band with pinv: a leg stretched because the reference point is
+  // out of reach (IK clamps d to 1, q3 = 0, |det| ~ 1e-18 of rounding noise) gets the pseudo-inverse, deterministically,
+  // instead of a full-scale torque whose sign depends on rounding inside LAPACK ("choices of this build").
+  // The lower end is raised to the rounding noise of det itself, 64 epsilon (sum |l|)^3, where that is larger (legs longer
+  // than ~0.4 m): below it the sign of det - and with it the sign of a saturated torque - is noise on any implementation.
+  // Rounds 2-3 switched at |det| <= 1e-9 (sum |l|)^3, five orders of magnitude earlier than the reference stops inverting.
+  const double ad = fabs(det), lsum = fabs(L1) + fabs(L2) + fabs(L3);
+  const double lo = fmax(2.220446049250313e-16, 1.4210854715202004e-14 * lsum * lsum * lsum);
   double qd[3];
-  if (fabs(det) > 1.0e-9 * lsum * lsum * lsum) {
+  if (ad >= lo && ad <= 4503599627370496.0) {
     const double id = FAST ? rcp_nr(det) : 1.0 / det;
     // inverse = adj / det; row r of the inverse dotted with vb
     qd[0] = id * (c00 * vb[0] + (J[2] * J[7] - J[1] * J[8]) * vb[1] + (J[1] * J[5] - J[2] * J[4]) * vb[2]);
@@ -610,7 +612,7 @@ QC_DEV void leg_swing_torque(CParams& P, const LegGeom& g, const double (&pb)[3]
   const double sig2 = x * x + rt2;
   const bool finite = (__builtin_fma(x, 0.0, __builtin_fma(y, 0.0, z * 0.0)) == 0.0);
   if (finite && rho2 > 0.0 && sig2 > 0.0) {
-    double d = num * g.inv_2l2l3;
+    double d = num / (2.0 * l2 * l3);  // (a true division, as the reference's: within a few ulps of d = 1 every ulp of d is a different knee angle)
     if (d > 1.0) d = 1.0;
     const double u = __builtin_fma(-d, d, 1.0);  // 1 - d^2 (d < -1: negative, the reference's sqrt gives NaN too)
     const double s3 = u == 0.0 ? -0.0 : -(u * rsqrt_nr(u)), c3 = d;

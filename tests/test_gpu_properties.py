@@ -444,6 +444,49 @@ def test_swing_reference_out_of_reach_takes_pinv(q, n):
     np.testing.assert_allclose(tau[i, leg], want, atol=1e-6 * max(20.0, np.abs(want).max()))
 
 
+def test_nearly_straight_knee_inverts_like_the_reference(q):
+    """ADVICE r3 / VERDICT r3 item 7: swing references that leave the knee some tens of ulps of its cosine (and more) from full
+    stretch (sin q3 = 1e-7 ... 1e-3; closer than ~10 ulps the rounding of the knee cosine d itself - contracted arithmetic on the
+    device, plain C in the oracle, whatever the reference's compiler did - decides between d < 1 and the clamp d = 1, i.e.
+    between a saturated torque and the pseudo-inverse, on any pair of implementations: tools/knee_ulps.py shows it).
+    |det J| is then 2e-9 or more - far above max(epsilon, 64 epsilon (sum |l|)^3), the bound
+    below which device and oracle answer with pinv - so both take arma::inv's closed-form branch, as the reference does:
+    joint-velocity targets up to 1e8 rad/s whose torques commander_node.cpp:526 clamps.  (Rounds 2-3 switched to the
+    rank-2 pseudo-inverse at |det| <= 1e-9 (sum |l|)^3 and the device alone dropped sigma_3 there.)  Clamped torques must
+    agree everywhere; unclamped ones wherever one ulp of the knee cosine - which the device's contracted arithmetic and
+    the oracle's plain C round differently - is below the tolerance, i.e. from sin q3 = 1e-4 up."""
+    from oracle import c_oracle as O
+    from quadruped_control_amd import workloads as W
+
+    P = q.cheetah_params(0.6)
+    n = 8192
+    b = W.with_swing_references(W.with_joint_angles(W.config3(n)))
+    rng = np.random.default_rng(5)
+    theta = np.array([1e-7, 3e-7, 1e-6, 1e-5, 1e-4, 1e-3])[rng.integers(0, 6, (n, 4))]
+    qt = np.stack([rng.uniform(-0.3, 0.3, (n, 4)), rng.uniform(0.2, 1.0, (n, 4)), -theta], axis=-1)
+    kin = O.default_kinematics()
+    pb = np.array([[O.leg_fk(leg, qt[i, leg], kin) for leg in range(4)] for i in range(n)])
+    R = b["Rwb"].reshape(n, 3, 3)
+    b["swing_pos"] = np.ascontiguousarray(np.einsum("nij,nkj->nki", R, pb + b["x"][:, None, :]).reshape(n, 12))  # pos = Rwb (p_b + x)
+    sw = b["stance"] == 0
+    for limit in (20.0, 1.0e12):
+        kin.tau_min, kin.tau_max = -limit, limit
+        ctl = q.BalanceController.from_params(P)
+        ctl.set_kinematics(tau_min=-limit, tau_max=limit)
+        o = ctl.control_batch_host(b, want_torques=True)
+        ref = O.tick_swing_batch(P, b, kin=kin, threads=8)
+        tau, rt = o["joint_tau"].reshape(n, 4, 3), ref["joint_tau"].reshape(n, 4, 3)
+        assert np.isfinite(tau[sw]).all() and np.array_equal(o["status"], ref["status"])
+        if limit == 20.0:
+            assert np.max(np.abs(tau - rt)[sw]) < 1e-6 * 20.0
+            assert (np.abs(rt[sw]).max(axis=-1) == 20.0).mean() > 0.9  # saturated: that is what a nearly singular J does in the reference
+        else:
+            m = sw & (theta >= 1e-4)
+            scale = np.maximum(20.0, np.abs(rt).max(axis=-1, keepdims=True))
+            assert np.max((np.abs(tau - rt) / scale)[m]) < 1e-6
+            assert np.abs(rt[sw & (theta < 1e-6)]).max() > 1e6 and np.abs(tau[sw & (theta < 1e-6)]).max() > 1e6  # the inverse, not a rank-2 pseudo-inverse
+
+
 @pytest.mark.parametrize("n", [600, 36000, 140000])  # G = 4; G = 2 single fill; G = 2 persistent waves (dense restock)
 def test_on_device_swing_planning_multi_tick(q, n):
     """SURVEY 8f rank 4, stateful half: foothold planner + sextic swing trajectories kept in a

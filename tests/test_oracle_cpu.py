@@ -312,3 +312,57 @@ def test_batch_kkt_certificate_accepts_the_oracle_and_rejects_perturbations():
     swing_rows = np.flatnonzero(b["stance"][:, 1] == 0)[:5]
     bad = grf.copy(); bad[swing_rows, 3] = 1e-12
     assert kkt_batch(P, b, bad)["swing_nonzero"][swing_rows].all()
+
+
+def test_inv_pinv_switch_has_numbers():
+    """INTEGRATION.md, "choices of this build", row 2: where legJacobianInverse (kinematics.cpp:190-204)
+    stops inverting.  arma::inv of a 3x3 is closed-form while epsilon <= |det| <= 1 / epsilon and goes to LAPACK below
+    that, which "succeeds" with a 1 / sigma_3-sized inverse unless a pivot is exactly zero; only then arma::pinv answers.
+    The oracle (and the device) invert down to max(epsilon, 64 epsilon (sum |l|)^3) and answer everything below with
+    pinv.  This test walks a leg towards full stretch and puts numbers on both ends of the band in between:
+      * nearly straight but reachable (|det| above the bound): the oracle inverts, like the reference - joint-velocity
+        targets of 1e4 ... 1e8 rad/s whose torque commander_node.cpp:526 clamps to +-tau_max on every implementation;
+      * out of reach (IK clamps d to 1: exact rank loss, |det| = rounding noise ~1e-18): the oracle returns pinv(J) v, a
+        bounded torque; LAPACK on the same J (numpy.linalg.inv = getrf + getri, what arma::inv falls back to) either
+        reports singularity or returns entries > 1e12, i.e. the reference's answer there is pinv or a full-scale clamped
+        torque depending on rounding - the one place where this build's torque can differ from the reference's by 2 tau_max."""
+    kin = O.default_kinematics()
+    eps = np.finfo(float).eps
+    hip = np.array(kin.hip).reshape(4, 3)
+    links = np.array(kin.links).reshape(4, 3)
+    vel = np.array([0.3, -0.2, 0.25])
+    rows = []
+    for leg in range(4):
+        det_lo = max(eps, 64 * eps * np.abs(links[leg]).sum() ** 3)
+        assert 1e-15 < det_lo < 3e-15  # (sum |l|)^3 = 0.139: the noise floor, not Armadillo's bare epsilon, is the bound for this robot
+        for theta in (1e-3, 1e-5, 1e-7, 3e-8):  # knee angle off straight
+            q = np.array([0.15 if leg < 2 else -0.15, 0.6, -theta])
+            target = O.leg_fk(leg, q, kin)
+            qr = O.leg_ik(leg, target, kin)
+            J = O.leg_jacobian(leg, qr, kin)
+            det = np.linalg.det(J)
+            assert abs(det) > 100 * det_lo and qr[2] != 0.0  # reachable: far above the bound even one ulp of d from straight
+            tau = O.swing_torque(leg, np.eye(3), np.zeros(3), target, vel, qr, np.zeros(3), kin)  # (measured state = IK solution: only kd qd remains)
+            want = np.array(kin.jc_kd) * np.linalg.solve(J, vel)
+            np.testing.assert_allclose(tau, want, rtol=1e-5, atol=1e-9)
+            rows.append((leg, theta, abs(det), np.abs(tau).max()))
+            assert np.abs(tau).max() > 20.0 * (1e-4 / theta)  # far beyond tau_max: clamped the same way everywhere
+        # out of reach: exact rank loss
+        q = np.array([0.15 if leg < 2 else -0.15, 0.6, 0.0])
+        target = hip[leg] + (O.leg_fk(leg, q, kin) - hip[leg]) * 1.3
+        qr = O.leg_ik(leg, target, kin)
+        J = O.leg_jacobian(leg, qr, kin)
+        assert qr[2] == 0.0 and abs(np.linalg.det(J)) < det_lo / 50
+        tau = O.swing_torque(leg, np.eye(3), np.zeros(3), target, vel, qr, np.zeros(3), kin)
+        want = np.array(kin.jc_kd) * (np.linalg.pinv(J, rcond=3 * eps) @ vel)
+        np.testing.assert_allclose(tau, want, atol=1e-9)
+        assert np.abs(tau).max() < 20.0  # bounded: inside the torque limits for this velocity
+        try:
+            lapack = np.abs(np.linalg.inv(J)).max()  # what arma::inv's LAPACK fallback would hand back
+        except np.linalg.LinAlgError:
+            lapack = np.inf  # exact zero pivot: the reference reaches pinv as well
+        assert lapack > 1e12
+        rows.append((leg, 0.0, abs(np.linalg.det(J)), np.abs(tau).max()))
+    # the band between the bound and exact rank loss cannot be entered through IK at all: the knee cosine d takes no value
+    # between 1 - 2^-53 (|det| ~ 3e-10) and 1
+    assert min(r[2] for r in rows if r[1] > 0) > 1e-11
