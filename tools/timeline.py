@@ -54,6 +54,22 @@ for k, nm in enumerate(("entry -> inputs landed", "inputs landed -> solve done",
     print("  %-34s mean %6.2f  p10 %6.2f  p50 %6.2f  p90 %6.2f  max %6.2f us" % (nm, v.mean(), *np.percentile(v, [10, 50, 90]), v.max()))
 slots = len(np.unique(hw))
 print("  distinct hardware wave slots used: %d; workgroups per slot: mean %.2f max %d" % (slots, blocks / slots, np.unique(hw, return_counts=True)[1].max()))
+# Where the launch's wave-slot time goes: a slot is USEFUL while its workgroup solves or flushes; what is
+# lost splits into (a) the first round's load burst - every slot of the first round waiting for its inputs -, (b) the loads of
+# the later rounds (a slot held by a workgroup whose inputs have not landed, while the chip is otherwise busy) and (c) the
+# final tail - slots that stay empty because no workgroup is left to start.  In microseconds of the whole chip
+# (slot-microseconds / slots), so the three figures plus "useful" add up to the launch span.
+first_round = np.argsort(us[:, 0])[:slots]  # the workgroups that started on an empty chip
+is_first = np.zeros(blocks, bool); is_first[first_round] = True
+load = us[:, 1] - us[:, 0]
+burst = load[is_first].sum() / slots
+later = load[~is_first].sum() / slots
+useful = (us[:, 3] - us[:, 1]).sum() / slots
+print("  slot-time split [us of the whole chip]: useful (solve + flush) %.1f | first-round load burst %.1f | loads of later rounds %.1f | "
+      "empty slots (final tail + gaps between workgroups) %.1f  (sum = span %.1f)" % (useful, burst, later, span - useful - burst - later, span))
+last_start = us[:, 0].max()
+print("  last workgroup starts at %.1f us; from then on %.1f us of tail; mean resident workgroups over the launch %.2f per slot" %
+      (last_start, span - last_start, (us[:, 3] - us[:, 0]).sum() / slots / span))
 if brief:
     sys.exit(0)
 edges = np.arange(0, np.ceil(span) + 1)
