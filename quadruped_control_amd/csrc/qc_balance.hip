@@ -632,31 +632,73 @@ QC_DEV void task_rwb(const BatchIn& in, const double* __restrict__ Rplanes, int 
 struct TorquePre {
   double q[12];
 };
-template <int SP>
+// Few robots in the stock of a lane-group kernel (chain-bound batches: four racing lane groups hold FOUR robots): the legs are
+// spread over the lanes of the robot's group, as the force stores are - one robot per lane would walk a lane through all
+// four legs while 60 lanes idle (measured: +2 us on the 4 096-robot fused tick).
+template <int G>
+QC_DEV bool torque_by_group(int out_n) { return G > 1 && out_n <= 64 / G; }
+template <int SP, int G, bool STR>
 QC_DEV void torque_prefetch(const BatchIn& in, const double* __restrict__ sout, int out_n, int lane, TorquePre& T) {
-  if (lane < out_n) {
+  if (torque_by_group<G>(out_n)) {
+    constexpr int FPL = 4 / G;
+    const int grp = lane_group<G, STR>(lane);
+    if (grp < out_n) {
+      const long idx = __double_as_longlong(sout[OUT_IDX * SP + grp]);
+      const double* qp = in.joint_q + 12 * idx + 3 * FPL * lane_member<G, STR>(lane);
+#pragma unroll
+      for (int k = 0; k < 3 * FPL; k++) T.q[k] = qp[k];
+    }
+  } else if (lane < out_n) {
     const long idx = __double_as_longlong(sout[OUT_IDX * SP + lane]);
     const double* qp = in.joint_q + 12 * idx;
 #pragma unroll
     for (int k = 0; k < 12; k++) T.q[k] = qp[k];
   }
 }
-template <int SP, bool RLDS>
+// the stance-leg torque map of NL legs of the robot in `slot`, from leg0 on (their joint angles in q[0 .. 3 NL))
+template <int SP, bool RLDS, int NL, bool RUNTIME_LEG>
+QC_DEV void stance_legs(CParams& P, const BatchIn& in, const BatchOut& out, const double* __restrict__ sout, const double* __restrict__ Rplanes, int slot,
+                        int leg0, bool have_swing, const double (&q)[12]) {
+  const long idx = __double_as_longlong(sout[OUT_IDX * SP + slot]);
+  const unsigned long long sw = (unsigned long long)__double_as_longlong(sout[OUT_STAT * SP + slot]);
+  const uint32_t stance = (uint32_t)((unsigned long long)__double_as_longlong(sout[OUT_WORD * SP + slot]) >> 32);
+  const int st_out = (stance & 0x100u) ? (int)QC_NOT_PD : (int)(uint32_t)sw;
+  double R[9];
+  task_rwb<SP, RLDS>(in, Rplanes, slot, idx, R);
+  // Branch-free over the legs on purpose: a wave of a one-round launch has its SIMD to itself and a leg's three sincos are
+  // serial polynomial chains - interleaved they issue back to back, one leg at a time behind a "does any lane need this
+  // leg" branch they ran at ~10 cycles per instruction (8.8 k cycles for the four legs, 6.2 k now).
+  LegTrig tr[NL];
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+    const double qa[3] = {q[3 * i], q[3 * i + 1], q[3 * i + 2]};
+    tr[i] = leg_trig(qa);
+  }
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+    const int leg = leg0 + i;
+    const bool stl = (stance >> leg) & 1u;
+    const bool todo = !(have_swing && !stl);  // (a swing leg with swing references belongs to the swing tasks)
+    const bool st = stl && st_out == QC_SOLVED;
+    double f[3], fb[3], tau[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) f[k] = sout[(OUT_F + 3 * leg + k) * SP + slot];
+#pragma unroll
+    for (int r = 0; r < 3; r++) fb[r] = st ? -(R[r] * f[0] + R[3 + r] * f[1] + R[6 + r] * f[2]) : 0.0;  // BC.cpp:218-232
+    if constexpr (RUNTIME_LEG) leg_jt_force(leg_geom(P, leg), tr[i], fb, tau);
+    else leg_jt_force(P, i, tr[i], fb, tau);  // (compile-time leg: the constants are scalar operands)
+    if (todo) store_tau(P, out, idx, leg, tau, st);
+  }
+}
+template <int SP, bool RLDS, int G, bool STR>
 QC_DEV void torque_pass(const DevParams* __restrict__ Pg, const BatchIn& in, const BatchOut& out, const double* __restrict__ sout, int out_n, int lane,
                         const double* __restrict__ Rplanes, TorquePre& Q) {
   QC_CLK_ABS(8, 13);
   unsigned char* const tl = reinterpret_cast<unsigned char*>(const_cast<double*>(sout) + OUT_PLANES * SP);  // (TASK_DOUBLES behind the planes)
   const bool have_swing = in.swing_pos || in.swing_state;
   const bool mine = lane < out_n;
-  long idx = 0;
   uint32_t stance = 0xFu;
-  int st_out = QC_NOT_PD;
-  if (mine) {
-    idx = __double_as_longlong(sout[OUT_IDX * SP + lane]);
-    const unsigned long long sw = (unsigned long long)__double_as_longlong(sout[OUT_STAT * SP + lane]);
-    stance = (uint32_t)((unsigned long long)__double_as_longlong(sout[OUT_WORD * SP + lane]) >> 32);
-    st_out = (stance & 0x100u) ? (int)QC_NOT_PD : (int)(uint32_t)sw;
-  }
+  if (mine) stance = (uint32_t)((unsigned long long)__double_as_longlong(sout[OUT_WORD * SP + lane]) >> 32);
   // the swing-leg tasks of the wave, leg-major (neighbouring lanes touch neighbouring robots): one byte each, slot << 2 | leg
   int ns = 0;
   if (have_swing) {
@@ -682,35 +724,18 @@ QC_DEV void torque_pass(const DevParams* __restrict__ Pg, const BatchIn& in, con
   }
   asm volatile("" ::: "memory");  // (... and requested above this line, not behind the stance legs' arithmetic)
   QC_CLK_ABS(13, 15);
-  // stance legs (and the swing legs of a batch without swing references: zero torque), one robot per lane:
-  // tau = clamp(J^T f_body), kinematics.cpp:219-231, commander_node.cpp:511-526
+  // stance legs (and the swing legs of a batch without swing references: zero torque), one robot per lane - or, with few
+  // robots in a lane-group kernel, the legs of a robot spread over its group: tau = clamp(J^T f_body), kinematics.cpp:219-231,
+  // commander_node.cpp:511-526
   {
     CParams& P = *QC_PARAMS_HERE(Pg);
-    double R[9];
-    if (mine) {
-      task_rwb<SP, RLDS>(in, Rplanes, lane, idx, R);
-      // Branch-free over the four legs on purpose: a wave of a one-round launch has its SIMD to itself and a leg's three
-      // sincos are serial polynomial chains - twelve of them interleaved issue back to back, one leg at a time behind a
-      // "does any lane need this leg" branch they ran at ~10 cycles per instruction (8.8 k cycles for the four legs).
-      LegTrig tr[4];
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const double qa[3] = {Q.q[3 * i], Q.q[3 * i + 1], Q.q[3 * i + 2]};
-        tr[i] = leg_trig(qa);
+    if (torque_by_group<G>(out_n)) {
+      if constexpr (G > 1) {
+        const int grp = lane_group<G, STR>(lane);
+        if (grp < out_n) stance_legs<SP, RLDS, 4 / G, true>(P, in, out, sout, Rplanes, grp, (4 / G) * lane_member<G, STR>(lane), have_swing, Q.q);
       }
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const bool stl = (stance >> i) & 1u;
-        const bool todo = !(have_swing && !stl);  // (a swing leg with swing references belongs to the swing tasks below)
-        const bool st = stl && st_out == QC_SOLVED;
-        double f[3], fb[3], tau[3];
-#pragma unroll
-        for (int k = 0; k < 3; k++) f[k] = sout[(OUT_F + 3 * i + k) * SP + lane];
-#pragma unroll
-        for (int r = 0; r < 3; r++) fb[r] = st ? -(R[r] * f[0] + R[3 + r] * f[1] + R[6 + r] * f[2]) : 0.0;  // BC.cpp:218-232
-        leg_jt_force(P, i, tr[i], fb, tau);
-        if (todo) store_tau(P, out, idx, i, tau, st);
-      }
+    } else if (mine) {
+      stance_legs<SP, RLDS, 4, false>(P, in, out, sout, Rplanes, lane, 0, have_swing, Q.q);
     }
   }
   QC_CLK_ABS(15, 14);
@@ -737,7 +762,7 @@ QC_DEV void flush_out(const DevParams* __restrict__ Pg, const BatchIn& in, const
   TorquePre tq;
   if constexpr (KIN) {
     if (out.joint_tau) {
-      torque_prefetch<SP>(in, sout, out_n, lane, tq);
+      torque_prefetch<SP, G, STR>(in, sout, out_n, lane, tq);
       asm volatile("" ::: "memory");  // (requested HERE: left alone, the compiler sinks these loads to their first use, behind the swing inputs)
     }
   }
@@ -752,7 +777,7 @@ QC_DEV void flush_out(const DevParams* __restrict__ Pg, const BatchIn& in, const
     store_from_stock<KIN, 4, SP, RLDS>(P, in, out, sout, lane, 0, RLDS ? Rplanes + lane : nullptr);
   }
   if constexpr (KIN) {
-    if (out.joint_tau) torque_pass<SP, RLDS>(Pg, in, out, sout, out_n, lane, Rplanes, tq);
+    if (out.joint_tau) torque_pass<SP, RLDS, G, STR>(Pg, in, out, sout, out_n, lane, Rplanes, tq);
   }
 }
 
