@@ -639,6 +639,9 @@ template <int G>
 QC_DEV bool torque_by_group(int out_n) { return G > 1 && out_n <= 64 / G; }
 template <int SP, int G, bool STR>
 QC_DEV void torque_prefetch(const BatchIn& in, const double* __restrict__ sout, int out_n, int lane, TorquePre& T) {
+  // (defined in every lane and on both paths: an array written to different extents on two paths stays in memory - scratch)
+#pragma unroll
+  for (int k = 0; k < 12; k++) T.q[k] = 0.0;
   if (torque_by_group<G>(out_n)) {
     constexpr int FPL = 4 / G;
     const int grp = lane_group<G, STR>(lane);
