@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #define QC_TL_MAX (1 << 16)
 __device__ unsigned long long qc_tl[QC_TL_MAX * 5];
+__device__ unsigned long long qc_tl_w1[QC_TL_MAX];  // hardware slot of the workgroup's SECOND wave (two-wave workgroups of the paired kernel)
 #define QC_TL_STAMP(k)                                                                                   \
   do {                                                                                                   \
     if (threadIdx.x == 0 && blockIdx.x < QC_TL_MAX) qc_tl[blockIdx.x * 5 + (k)] = __builtin_amdgcn_s_memrealtime(); \
@@ -19,6 +20,12 @@ __device__ unsigned long long qc_tl[QC_TL_MAX * 5];
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));                                   \
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));                                 \
       qc_tl[blockIdx.x * 5 + 4] = ((unsigned long long)xcc << 32) | hw;                                  \
+    }                                                                                                    \
+    if (threadIdx.x == 64 && blockIdx.x < QC_TL_MAX) {                                                   \
+      unsigned hw, xcc;                                                                                  \
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));                                   \
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));                                 \
+      qc_tl_w1[blockIdx.x] = ((unsigned long long)xcc << 32) | hw;                                       \
     }                                                                                                    \
   } while (0)
 #define QC_CLK(from, to)                                                                                 \
@@ -41,6 +48,10 @@ __device__ unsigned long long qc_tl[QC_TL_MAX * 5];
 #define QC_CLK_PIN(arr)
 #include "../quadruped_control_amd/csrc/qc_balance.hip"
 
+extern "C" int qc_timeline_read_w1(unsigned long long* out, long blocks) {
+  if (blocks > QC_TL_MAX) blocks = QC_TL_MAX;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(qc_tl_w1), sizeof(unsigned long long) * blocks) == hipSuccess ? 0 : -1;
+}
 extern "C" int qc_timeline_read(unsigned long long* out, long blocks) {
   if (blocks > QC_TL_MAX) blocks = QC_TL_MAX;
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(qc_tl), sizeof(unsigned long long) * 5 * blocks) == hipSuccess ? 0 : -1;

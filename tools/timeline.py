@@ -52,6 +52,16 @@ ph = np.stack([us[:, 1] - us[:, 0], us[:, 2] - us[:, 1], us[:, 3] - us[:, 2], us
 for k, nm in enumerate(("entry -> inputs landed", "inputs landed -> solve done", "flush (transform + stores acked)", "whole workgroup")):
     v = ph[:, k]
     print("  %-34s mean %6.2f  p10 %6.2f  p50 %6.2f  p90 %6.2f  max %6.2f us" % (nm, v.mean(), *np.percentile(v, [10, 50, 90]), v.max()))
+if info["mode"] == 3:  # two-wave workgroups: do the two waves of a workgroup share a SIMD?  (HW_ID: simd_id = bits 5:4, cu_id 11:8, se 15:13; XCC in the high word)
+    b1 = (C.c_ulonglong * blocks)()
+    assert ctl._lib.qc_timeline_read_w1(b1, blocks) == 0
+    h1 = np.array(list(b1), dtype=np.uint64)
+    same_cu = ((hw >> np.uint64(8)) & np.uint64(0xFF)) == ((h1 >> np.uint64(8)) & np.uint64(0xFF))
+    same_simd = same_cu & (((hw >> np.uint64(4)) & np.uint64(3)) == ((h1 >> np.uint64(4)) & np.uint64(3)))
+    simd_of = lambda h: (h >> np.uint64(32)) * np.uint64(1 << 16) + ((h >> np.uint64(4)) & np.uint64(0xFFF))  # (xcc, se, cu, simd)
+    occ = np.unique(np.concatenate([simd_of(hw), simd_of(h1)]), return_counts=True)[1]
+    print("  two-wave workgroups: both waves on one SIMD in %.1f %% of the workgroups; SIMDs used %d, waves per used SIMD: mean %.2f max %d" %
+          (100.0 * same_simd.mean(), len(occ), occ.mean(), occ.max()))
 slots = len(np.unique(hw))
 print("  distinct hardware wave slots used: %d; workgroups per slot: mean %.2f max %d" % (slots, blocks / slots, np.unique(hw, return_counts=True)[1].max()))
 # Where the launch's wave-slot time goes: a slot is USEFUL while its workgroup solves or flushes; what is
