@@ -62,6 +62,13 @@ if info["mode"] == 3:  # two-wave workgroups: do the two waves of a workgroup sh
     occ = np.unique(np.concatenate([simd_of(hw), simd_of(h1)]), return_counts=True)[1]
     print("  two-wave workgroups: both waves on one SIMD in %.1f %% of the workgroups; SIMDs used %d, waves per used SIMD: mean %.2f max %d" %
           (100.0 * same_simd.mean(), len(occ), occ.mean(), occ.max()))
+simd_key = (hw >> np.uint64(32)) * np.uint64(1 << 16) + ((hw >> np.uint64(4)) & np.uint64(0xFFF))  # (xcc, se / sh, cu, simd) of the workgroup's first wave
+cu_key = (hw >> np.uint64(32)) * np.uint64(1 << 16) + ((hw >> np.uint64(8)) & np.uint64(0xFF))
+first = np.argsort(us[:, 0])[:min(blocks, 2048)]  # the workgroups that started on an empty chip
+oc = np.unique(simd_key[first], return_counts=True)[1]
+occ_cu = np.unique(cu_key[first], return_counts=True)[1]
+print("  first %d workgroups (first waves): %d SIMDs used, workgroups per used SIMD mean %.2f max %d (histogram %s); %d CUs used, per CU min %d max %d" %
+      (len(first), len(oc), oc.mean(), oc.max(), np.bincount(oc).tolist(), len(occ_cu), occ_cu.min(), occ_cu.max()))
 slots = len(np.unique(hw))
 print("  distinct hardware wave slots used: %d; workgroups per slot: mean %.2f max %d" % (slots, blocks / slots, np.unique(hw, return_counts=True)[1].max()))
 # Where the launch's wave-slot time goes: a slot is USEFUL while its workgroup solves or flushes; what is
