@@ -47,7 +47,10 @@ for name, b, warm, n in work:
             ctl.set_tuning(**v)
         except ValueError as e:
             print(name, v, "skipped:", e); continue
-        info = ctl.query_launch(n, warm=warm is not None)
+        try:
+            info = ctl.query_launch(n, warm=warm is not None)
+        except RuntimeError as e:  # persistent 6x6 kernels: -DQC_PERSISTENT_6X6=1 builds only
+            print(name, v, "skipped:", str(e).split(":")[-1].strip()[:90]); continue
         try:
             us, out = timeit(ctl, b, warm)
         except Exception as e:

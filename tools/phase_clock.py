@@ -14,7 +14,7 @@ cfg = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 # argv[3] = lanes per robot, argv[4] = 1 forces the persistent kernel
 tune = dict(group=int(sys.argv[3]) if len(sys.argv) > 3 else 4)
 if len(sys.argv) > 4 and sys.argv[4] == "1":
-    tune["one_fill"] = 0
+    tune["one_fill"] = 0  # (6x6 forms: needs a -DQC_PERSISTENT_6X6=1 build of the clock library, otherwise the launch is refused)
 for kv in sys.argv[5:]:  # further tuning keys, e.g. race=0
     k, v = kv.split("=")
     tune[k] = float(v)
