@@ -136,12 +136,6 @@ def time_launches(launches, steps, warmup, dist=None, warm_all=False):
     for i in range(steps):
         launches[(w + i) % m]()  # continues where the warm-up stopped: with K distinct sets the first timed ones were never touched
     ev1.record()
-    # The host waits for the K-th step by polling the closing event, then synchronises (which returns at once): a blocking
-    # synchronize alone wakes the host thread ~25 us after the GPU is done - nothing to do with the path, and 5 % of a 20-step
-    # region of 21-us steps.  (QC_BENCH_NO_SPIN=1 leaves the wake-up to synchronize.)
-    if os.environ.get("QC_BENCH_NO_SPIN") != "1":
-        while not ev1.query():
-            pass
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0  # this rank's K steps; the caller takes the MAX over ranks
     if dist is not None:
