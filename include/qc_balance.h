@@ -118,8 +118,10 @@ typedef struct qc_batch_out {
   int32_t* iterations;  /* [n] optional (may be NULL): working-set recalculations used */
   /* ABI v2, optional (NULL = unused; needs qc_batch_in.joint_q).  Stance-leg joint torques [n][4][3]:
    * tau = J(q_leg)^T f_body (QuadrupedKinematics::jacobianTransposeControl, kinematics.cpp:219-231 with
-   * legJacobian :162-188), clamped to [tau_min, tau_max] as commander_node.cpp:523-526; swing legs (whose
-   * torques the reference takes from its joint PD, out of scope) and failed instances get 0. */
+   * legJacobian :162-188), clamped to [tau_min, tau_max] as commander_node.cpp:523-526; failed instances get 0.
+   * Swing legs get 0 as well unless swing references are given (qc_batch_in.swing_pos / swing_vel / joint_qdot, or
+   * swing_state): then their entries hold the reference's swing-leg joint PD torque (commander_node.cpp:482-504),
+   * whatever the QP's status. */
   double* joint_tau;
 } qc_batch_out;
 

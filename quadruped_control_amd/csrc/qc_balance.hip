@@ -537,19 +537,16 @@ QC_DEV int restock(const DevParams* __restrict__ Pg, const BatchIn& in, const ui
 
 // ---- the torque pass of the widened tick (SURVEY 8f rows 1 + 4): joint_tau of the robots parked in the output stock ----------
 // commander_node.cpp:482-531: swing legs get IK -> J^-1 -> joint PD torques, stance legs tau = J^T f_body, all clamped.
-// A (robot, leg) pair is a TASK, and a wave's tasks are sorted by kind before any of them runs: the swing-leg tasks are
-// packed into consecutive lanes and executed together, then the stance-leg tasks.  Round 3 looped over the four legs with one
-// robot per lane and a per-lane `if (swing) ... else ...`: in a batch of mixed contact states every leg is swinging in SOME
-// lane, so every lane walked through IK + J^-1 + PD and through J^T four times - eight passes of code for what is, for a trot,
-// two passes of the swing chain and two of the stance map (the 64 robots of a wave hold ~128 tasks of each kind).
-// The lists (one byte per task: slot << 2 | leg; swing tasks from the front, stance tasks from the back of a 256-byte array
-// behind the stock planes) are built with ballots and mbcnt, leg-major, so neighbouring lanes still touch neighbouring robots.
-
-// What makes the pass cheap is mostly WHEN its loads are issued (a wave of a one-round launch has its SIMD to itself: a
+// Round 3 looped over the four legs with one robot per lane and a per-lane `if (swing) ... else ...`: in a batch of mixed
+// contact states every leg is swinging in SOME lane, so every lane walked through IK + J^-1 + PD and through J^T four times.
+// Now a swinging (robot, leg) pair is a TASK: the wave's swing tasks are listed (one byte each: slot << 2 | leg, in a 256-byte
+// array behind the stock planes; built with ballots and mbcnt, leg-major, so neighbouring lanes still touch neighbouring
+// robots) and run in consecutive lanes - one or two passes of the ~650-instruction swing chain instead of four.  The cheap
+// stance map (J^T f: three sincos and a dozen products per leg) stays one robot per lane: its loads are one coalesced batch and
+// its per-leg constants scalar operands.
+// What makes the pass cheap is as much WHEN its loads are issued (a wave of a one-round launch has its SIMD to itself: a
 // dependent global load is ~1 us of nothing): the stance legs' joint angles are requested before the force stores, the first
 // swing pass's inputs before the stance legs are computed, and every further swing pass's inputs while the previous one computes.
-// So the cheap stance map (J^T f: three sincos and a dozen products per leg) stays one robot per lane - its loads are one
-// coalesced batch and its per-leg constants scalar - and only the swing chain (IK, J^-1, PD: ~650 instructions) is compacted.
 QC_DEV void store_tau(CParams& P, const BatchOut& out, long idx, int leg, const double (&tau)[3], bool emit) {
   double* to = out.joint_tau + 12 * idx + 3 * leg;
 #pragma unroll

@@ -547,7 +547,8 @@ QC_DEV double wrap_PI(double rad) {
 
 // legJacobianInverse(q_ref) * vb (kinematics.cpp:190-204: arma::inv as the closed-form inverse; arma::pinv if singular) and
 // JointController::control (joint_controller.cpp:28-36), from the reference angles `qr` and the sines / cosines of
-// (q1, q2, q2 + q3) at q_ref.  WRAP = the wrap functions (the reference's or the multiplication form).
+// (q1, q2, q2 + q3) at q_ref.  FAST: reciprocal by Newton steps and the multiplication-form wraps (the trig-free path of
+// leg_swing_torque); otherwise the reference's division and wrap functions (its reference-shaped fallback).
 template <bool FAST>
 QC_DEV void swing_pd(CParams& P, const LegGeom& g, const LegTrig& t, const double (&qr)[3], const double (&vb)[3], const double* __restrict__ q,
                      const double* __restrict__ qdot, double (&tau)[3]) {
