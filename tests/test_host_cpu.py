@@ -173,3 +173,28 @@ def test_device_generator_matches_the_host_generator_on_cpu():
             assert np.max(np.abs(dd - h[k])) < 1e-15
         else:
             assert np.array_equal(dd, h[k]), k
+
+
+def test_bench_tick_workloads_and_byte_counts():
+    """bench.py's SURVEY 8(f) tick workloads: the algorithmic byte counts the roofline is priced with,
+    the number of rotating sets of the cold-cache protocol, and the shape of the generated batches."""
+    import bench
+
+    assert bench.bytes_per_robot(False) == 488 == 48 * 8 + 4 + 12 * 8 + 4
+    assert bench.bytes_per_robot(True) == 496
+    assert bench.bytes_per_robot(False, True) == 584 == 488 + 96                      # + joint_tau
+    assert bench.bytes_per_robot(False, "full") == 964 == (384 + 32 + 96 + 224) + (96 + 4 + 96 + 32)
+    assert bench.rotation_sets(4096, False) == 269 and bench.rotation_sets(65536, False) == 17
+    assert bench.rotation_sets(65536, False, "full") == (512 << 20) // (964 * 65536) + 1 == 9
+    assert bench.rotation_sets(262144, False, "full") == 3 and bench.rotation_sets(2097152, False) == 1
+    fused = bench.make_tick_batch(2, 64, 0, True)
+    assert "feet" not in fused and fused["joint_q"].shape == (64, 12) and fused["stance"].shape == (64, 4)
+    full = bench.make_tick_batch(3, 64, 128, "full", j=2)
+    assert {"joint_q", "joint_qdot", "gait_phase"} <= set(full) and not {"stance", "swing_pos", "swing_vel", "feet"} & set(full)
+    assert full["gait_phase"].shape == (64, 4) and (full["gait_phase"] >= 0).all() and (full["gait_phase"] < 1).all()
+    # rotation sets hold different robots of the same distribution; a shard is reproducible from its start index
+    other = bench.make_tick_batch(3, 64, 128, "full", j=0)
+    assert not np.array_equal(full["joint_q"], other["joint_q"])
+    np.testing.assert_array_equal(bench.make_tick_batch(3, 32, 160, "full", j=2)["joint_q"], full["joint_q"][32:])
+    assert "EPYC" in bench.cpu_model() or len(bench.cpu_model()) > 3
+    assert bench.oracle_build_flags().startswith(("gcc", "cc")) and "-ffp-contract=off" in bench.oracle_build_flags()
