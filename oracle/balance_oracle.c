@@ -591,14 +591,29 @@ int oracle_pinv3(const double* J, double* Jp) {
   double A[3][3], V[3][3];
   for (int i = 0; i < 3; i++)
     for (int j = 0; j < 3; j++) { A[i][j] = J[3 * i + j]; V[i][j] = (i == j) ? 1.0 : 0.0; }
+  /* A column whose norm has fallen below the tolerance that drops its singular value anyway (3 sigma_max epsilon, with the
+   * largest current column norm for sigma_max) is numerically zero and its DIRECTION is rounding noise: on an exactly
+   * rank-deficient J - a stretched leg, or the lateral clamp of kinematics.cpp:137-140, on some random kinematic models - the
+   * orthogonality test against such a column never settles (found by the round-4 tick fuzz: 60 sweeps ran out and the J^T
+   * fallback answered where Armadillo's pinv, numpy's and the device's return the rank-2 pseudo-inverse).  Pairs with such a
+   * column count as converged. */
   int converged = 0;
   for (int sweep = 0; sweep < 60 && !converged; sweep++) {
     converged = 1;
+    double cmax = 0.0;
+    for (int j = 0; j < 3; j++) {
+      const double c2 = A[0][j] * A[0][j] + A[1][j] * A[1][j] + A[2][j] * A[2][j];
+      if (c2 > cmax) cmax = c2;
+    }
+    const double zero2 = 9.0 * 2.220446049250313e-16 * 2.220446049250313e-16 * cmax;
     for (int p = 0; p < 2; p++)
       for (int q = p + 1; q < 3; q++) {
         double alpha = 0.0, beta = 0.0, gamma = 0.0;
         for (int i = 0; i < 3; i++) { alpha += A[i][p] * A[i][p]; beta += A[i][q] * A[i][q]; gamma += A[i][p] * A[i][q]; }
-        if (gamma == 0.0 || fabs(gamma) <= 2.220446049250313e-16 * sqrt(alpha * beta)) continue; /* orthogonal to working precision */
+        if (alpha <= zero2 || beta <= zero2) continue;
+        /* orthogonal to working precision: a three-term inner product carries up to ~3 epsilon of relative rounding error, so a
+         * bare epsilon makes two large columns at the noise floor swap the sign of gamma for ever (the same fuzz finding) */
+        if (gamma == 0.0 || fabs(gamma) <= 4.0 * 2.220446049250313e-16 * sqrt(alpha * beta)) continue;
         converged = 0;
         const double zeta = (beta - alpha) / (2.0 * gamma);
         const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
@@ -652,7 +667,9 @@ void oracle_swing_torque(const oracle_kinematics* k, int leg, const double* Rwb,
      * det - and of the saturated torque it leads to - is noise on any implementation) */
     const double lsum = fabs(k->links[3 * leg]) + fabs(k->links[3 * leg + 1]) + fabs(k->links[3 * leg + 2]);
     const double det_lo = fmax(2.220446049250313e-16, 1.4210854715202004e-14 * lsum * lsum * lsum);
-    int singular = !(fabs(det) >= det_lo && fabs(det) <= 4503599627370496.0);
+    /* (a NaN determinant - d < -1 in legInverseKinematics - is neither below nor above the band: the closed form divides the
+     * cofactors by NaN, and so does the elimination below: every entry of the inverse, hence every torque of the leg, is NaN) */
+    int singular = (fabs(det) < det_lo) || (fabs(det) > 4503599627370496.0);
     for (int i = 0; i < 3; i++)
       for (int j = 0; j < 3; j++) { M[i][j] = J[3 * i + j]; M[i][3 + j] = (i == j) ? 1.0 : 0.0; }
     for (int c = 0; c < 3 && !singular; c++) {

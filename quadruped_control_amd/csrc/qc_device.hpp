@@ -569,7 +569,10 @@ QC_DEV void swing_pd(CParams& P, const LegGeom& g, const LegTrig& t, const doubl
   const double ad = fabs(det), lsum = fabs(L1) + fabs(L2) + fabs(L3);
   const double lo = fmax(2.220446049250313e-16, 1.4210854715202004e-14 * lsum * lsum * lsum);
   double qd[3];
-  if (ad >= lo && ad <= 4503599627370496.0) {
+  // (a NaN determinant - a reference inside the inner reach limit, d < -1: sqrt(negative) in legInverseKinematics - is neither
+  // below nor above the band: Armadillo's closed form then divides the cofactors by NaN, every entry of the "inverse" is NaN and
+  // so are all three torques of the leg; written so that NaN takes this branch)
+  if (!(ad < lo) && !(ad > 4503599627370496.0)) {
     const double id = FAST ? rcp_nr(det) : 1.0 / det;
     // inverse = adj / det; row r of the inverse dotted with vb
     qd[0] = id * (c00 * vb[0] + (J[2] * J[7] - J[1] * J[8]) * vb[1] + (J[1] * J[5] - J[2] * J[4]) * vb[2]);
@@ -612,10 +615,12 @@ QC_DEV void leg_swing_torque(CParams& P, const LegGeom& g, const double (&pb)[3]
   const double rt2 = sc;  // rt^2
   const double sig2 = x * x + rt2;
   const bool finite = (__builtin_fma(x, 0.0, __builtin_fma(y, 0.0, z * 0.0)) == 0.0);
-  if (finite && rho2 > 0.0 && sig2 > 0.0) {
-    double d = num / (2.0 * l2 * l3);  // (a true division, as the reference's: within a few ulps of d = 1 every ulp of d is a different knee angle)
-    if (d > 1.0) d = 1.0;
-    const double u = __builtin_fma(-d, d, 1.0);  // 1 - d^2 (d < -1: negative, the reference's sqrt gives NaN too)
+  double d = num / (2.0 * l2 * l3);  // (a true division, as the reference's: within a few ulps of |d| = 1 every ulp of d is a different knee angle)
+  if (d > 1.0) d = 1.0;
+  // d < -1 (the reference point inside the inner reach limit; the reference clamps d > 1 only, kinematics.cpp:131-134) makes
+  // q3 and q2 NaN in the reference: that case goes the reference-shaped way below, where the NaNs propagate as they do there
+  if (finite && rho2 > 0.0 && sig2 > 0.0 && d >= -1.0) {
+    const double u = __builtin_fma(-d, d, 1.0);  // 1 - d^2 >= 0
     const double s3 = u == 0.0 ? -0.0 : -(u * rsqrt_nr(u)), c3 = d;
     const double rt = rt2 == 0.0 ? 0.0 : rt2 * rsqrt_nr(rt2);
     const double ir = rsqrt_nr(rho2);                 // 1 / |(y, z)|
@@ -640,8 +645,6 @@ QC_DEV void leg_swing_torque(CParams& P, const LegGeom& g, const double (&pb)[3]
     return;
   }
   // reference-shaped evaluation (rare, divergent)
-  double d = num / (2.0 * l2 * l3);
-  if (d > 1.0) d = 1.0;
   const double rt = sqrt(sc);
   double qr[3], s3, c3;
   qr[0] = right ? atan2(z, y) + atan2(rt, -l1) : -(atan2(z, -y) + atan2(rt, -l1));

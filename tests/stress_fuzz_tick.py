@@ -13,7 +13,7 @@ from oracle import c_oracle as O
 def run(batches=30, n=4096, budget_s=None, min_batches=3):
     """Returns (worst GRF error, worst torque error / tau_max, torque entries off by > 1e-6, status mismatches, batches done)."""
     rng = np.random.default_rng(999)
-    worst = 0.0; worst_f = 0.0; mism = 0; t0 = time.time(); flips = 0
+    worst = 0.0; worst_f = 0.0; mism = 0; t0 = time.time(); flips = 0; nan_mismatch = 0
     for bi in range(batches):
         if budget_s is not None and bi >= min_batches and time.time() - t0 > budget_s: bi -= 1; break
         P = q.cheetah_params(float(rng.choice([0.4, 0.6, 0.8])))
@@ -39,15 +39,24 @@ def run(batches=30, n=4096, budget_s=None, min_batches=3):
         scale = np.maximum(1.0, np.abs(ref["grf_body"]).max(axis=1, keepdims=True))
         ef = float((np.abs(o["grf_body"] - ref["grf_body"]) / scale)[okm].max()) if okm.any() else 0.0
         d = np.abs(o["joint_tau"] - ref["joint_tau"]) / tmax
+        # NaN on one side only: a swing reference within an ulp of the INNER reach limit (knee cosine d = -1, the leg folded onto
+        # itself) - legInverseKinematics clamps d > 1 only (kinematics.cpp:131-134), so d < -1 by an ulp is sqrt(negative) = NaN
+        # and d >= -1 a (singular, saturated) number, and which one it is depends on how d itself was rounded.
+        # Counted on their own: ~1 leg in 1e7 of this campaign's wild references.
+        one_nan = np.isnan(o["joint_tau"]) != np.isnan(ref["joint_tau"])
+        leg_nan = one_nan.reshape(n, 4, 3).any(axis=2, keepdims=True).repeat(3, axis=2).reshape(n, 12)
+        nan_mismatch += int(one_nan.sum())
+        d = np.where(leg_nan, 0.0, d)
         big = d > 1e-6
         flips += int(big.sum())
-        worst_f = max(worst_f, ef); worst = max(worst, float(d.max()))
+        worst_f = max(worst_f, ef); worst = max(worst, float(np.nanmax(d)))
         if ef > 1e-6 or big.any() or mism:
             i, j = np.unravel_index(np.argmax(d), d.shape)
             print("batch %d spread %.1f: grf err %.2e, torque err %.2e of tau_max (robot %d joint %d: gpu %.6f oracle %.6f, stance %s), %d entries > 1e-6, status mismatches %d" %
                   (bi, spread, ef, d.max(), i, j, o["joint_tau"][i, j], ref["joint_tau"][i, j], b["stance"][i], int(big.sum()), mism))
-    print("%d batches x %d robots in %.0f s: worst grf err %.2e, worst torque err %.2e of tau_max, entries > 1e-6: %d of %d, status mismatches %d" %
-          (bi + 1, n, time.time() - t0, worst_f, worst, flips, (bi + 1) * n * 12, mism))
+    print("%d batches x %d robots in %.0f s: worst grf err %.2e, worst torque err %.2e of tau_max, entries > 1e-6: %d of %d, status mismatches %d, "
+          "entries NaN on one side only (reference within an ulp of the inner reach limit): %d" %
+          (bi + 1, n, time.time() - t0, worst_f, worst, flips, (bi + 1) * n * 12, mism, nan_mismatch))
     return worst_f, worst, flips, mism, bi + 1
 
 

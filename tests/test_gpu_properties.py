@@ -426,6 +426,38 @@ def test_swing_tasks_fill_every_pass_of_the_torque_pass(q, n):
     assert np.all(o["grf_body"][st.sum(1) == 0] == 0.0) and np.any(o["joint_tau"][st.sum(1) == 0] != 0.0)
 
 
+def test_swing_reference_inside_the_inner_reach_limit(q):
+    """Round-4 tick fuzz finding: a swing reference closer to the hip than | |l2| - |l3| | (knee cosine d < -1, which
+    legInverseKinematics does not clamp, kinematics.cpp:131-134) makes q3, q2 and with them the whole leg's torques NaN in the
+    reference; the device's trig-free IK kept cos q3 = d finite and returned numbers for two of the three joints.  All three
+    must be NaN, the leg's neighbours and the robot's forces untouched, on every lane-group width."""
+    from oracle import c_oracle as O
+    from quadruped_control_amd import workloads as W
+
+    P = q.cheetah_params(0.6)
+    n = 3000
+    b = W.with_swing_references(W.with_joint_angles(W.config3(n)))
+    hip = np.array([[-0.196, 0.05, 0.0], [0.196, 0.05, 0.0], [-0.196, -0.05, 0.0], [0.196, -0.05, 0.0]])
+    rng = np.random.default_rng(8)
+    inside = rng.random((n, 4)) < 0.3
+    off = np.stack([rng.uniform(-0.012, 0.012, (n, 4)), np.where(np.arange(4) < 2, 0.077, -0.077)[None] + rng.uniform(-0.004, 0.004, (n, 4)),
+                    rng.uniform(-0.012, 0.012, (n, 4))], axis=-1)  # within ~1.7 cm of the hip-roll offset: d < -1 (inner limit 1.9 cm) or just outside
+    R = b["Rwb"].reshape(n, 3, 3)
+    pos_in = np.einsum("nij,nkj->nki", R, hip[None] + off + b["x"][:, None, :])
+    b["swing_pos"] = np.ascontiguousarray(np.where(inside[..., None], pos_in, b["swing_pos"].reshape(n, 4, 3)).reshape(n, 12))
+    ref = O.tick_swing_batch(P, b, threads=8)
+    sw = (b["stance"] == 0) & inside
+    nan_ref = np.isnan(ref["joint_tau"].reshape(n, 4, 3))
+    assert nan_ref[sw].all(axis=-1).mean() > 0.5  # most of the planted references are inside the limit
+    for group in (1, 2, 4):
+        o = q.BalanceController.from_params(P).set_tuning(group=group).control_batch_host(b, want_torques=True)
+        tau = o["joint_tau"].reshape(n, 4, 3)
+        assert np.array_equal(np.isnan(tau), nan_ref), group
+        m = ~nan_ref
+        assert np.abs(tau - ref["joint_tau"].reshape(n, 4, 3))[m].max() < 1e-6 * 20.0
+        assert np.array_equal(o["status"], ref["status"]) and np.isfinite(o["grf_body"]).all()
+
+
 @pytest.mark.parametrize("n", [900, 70000])  # 4 lanes per robot (one foot per lane) and one lane per robot
 def test_swing_reference_out_of_reach_takes_pinv(q, n):
     """legJacobianInverse's second branch (kinematics.cpp:194-196): a swing reference the leg cannot reach makes

@@ -366,3 +366,58 @@ def test_inv_pinv_switch_has_numbers():
     # the band between the bound and exact rank loss cannot be entered through IK at all: the knee cosine d takes no value
     # between 1 - 2^-53 (|det| ~ 3e-10) and 1
     assert min(r[2] for r in rows if r[1] > 0) > 1e-11
+
+
+def test_pinv3_converges_on_an_exactly_rank_deficient_jacobian():
+    """Found by the round-4 tick fuzz (batch 519 of tests/stress_fuzz_tick.py): on this stretched-leg Jacobian of a random
+    kinematic model (singular values 0.54, 0.46, 1e-17) the one-sided Jacobi sweeps of oracle_pinv3 never settled - the
+    orthogonality test against a column of norm 1e-17 is rounding noise - so the oracle fell through to J^T
+    (kinematics.cpp:198) where Armadillo's pinv (and the device) return the rank-2 pseudo-inverse; on two more (batches 3075,
+    3888) two LARGE columns at the noise floor kept swapping the sign of their inner product.  Columns below the truncation
+    tolerance now count as converged and the orthogonality test allows the inner product its own rounding error (4 epsilon)."""
+    found = (  # batches 519 (stretched leg), 3075 (lateral clamp, kinematics.cpp:137-140: two parallel columns), 3888 (stretched leg)
+        ('0x0.0p+0', '-0x1.d85eb9505ce1bp-2', '-0x1.bff7626ccb7bep-3', '0x1.f1e42b8af94a2p-3', '0x1.c9db5dd657bb5p-4',
+         '0x1.b233f87bcccb7p-5', '-0x1.97de8d5c16c7dp-2', '0x1.813938b676175p-4', '0x1.6d52709bd6727p-5'),
+        ('0x0.0p+0', '0x1.0000000000000p-55', '0x1.435907d076f24p-3', '-0x1.7ca32d7dde780p-8', '-0x1.9baaf35b4afccp-8',
+         '-0x1.7ebf12851ea29p-8', '-0x1.7a64289092931p-4', '-0x1.993d0df968237p-4', '-0x1.7c7cddfcebd82p-4'),
+        ('0x0.0p+0', '-0x1.abbd81fa189aep-3', '-0x1.4935e4b33f64fp-4', '0x1.83f9d0f42d538p-4', '-0x1.249903dc998e7p-2',
+         '-0x1.c2655e762894ep-4', '-0x1.8d3b08bec9c99p-3', '-0x1.f68e836a5d925p-3', '-0x1.82cb03a72ccc1p-4'))
+    for hexes in found:
+        J = np.array([float.fromhex(h) for h in hexes]).reshape(3, 3)
+        sv = np.linalg.svd(J, compute_uv=False)
+        assert sv[2] < 1e-16 < 0.1 < sv[1]
+        Jp, ok = O.pinv3(J)
+        assert ok
+        ref = np.linalg.pinv(J, rcond=3 * np.finfo(float).eps)
+        np.testing.assert_allclose(Jp, ref, atol=1e-12 * np.abs(ref).max())
+    # ... and over random exactly singular matrices (two parallel columns, a zero column, rank 1)
+    rng = np.random.default_rng(3)
+    for trial in range(20000):
+        A = rng.normal(size=(3, 3)) * 10.0 ** rng.uniform(-3, 1)
+        kind = trial % 4
+        if kind == 0: A[:, 2] = A[:, 1] * rng.normal()
+        elif kind == 1: A[:, rng.integers(3)] = 0.0
+        elif kind == 2: A = np.outer(A[:, 0], A[0])
+        else: A[2] = A[0] * rng.normal() + A[1] * rng.normal()
+        Ap, ok = O.pinv3(A)
+        assert ok, (trial, A)
+        ref = np.linalg.pinv(A, rcond=3 * np.finfo(float).eps)
+        np.testing.assert_allclose(Ap, ref, atol=1e-10 * max(1.0, np.abs(ref).max()))
+
+
+def test_reference_inside_the_inner_reach_limit_gives_nan_torques():
+    """legInverseKinematics clamps the knee cosine from above only (d > 1 -> 1, kinematics.cpp:131-134): a swing reference closer
+    to the hip than | |l2| - |l3| | has d < -1, q3 = atan2(-sqrt(1 - d^2), d) = NaN, q2 = NaN, the Jacobian at q_ref is NaN, and
+    Armadillo's closed-form inverse (cofactors over a NaN determinant) makes all three joint-velocity targets - hence all three
+    torques of the leg - NaN, which commander_node.cpp:526's two-compare clamp leaves NaN."""
+    kin = O.default_kinematics()
+    hip = np.array(kin.hip).reshape(4, 3)
+    links = np.abs(np.array(kin.links).reshape(4, 3))
+    for leg in range(4):
+        inner = abs(links[leg, 1] - links[leg, 2])  # 0.019 m
+        # a point at distance sqrt(l1^2 + (0.5 inner)^2) from the hip: in the leg's plane only half the inner limit away
+        target = hip[leg] + np.array([0.5 * inner, links[leg, 0] * (1 if leg < 2 else -1), 0.0])
+        qr = O.leg_ik(leg, target, kin)
+        assert np.isfinite(qr[0]) and np.isnan(qr[1]) and np.isnan(qr[2])
+        tau = O.swing_torque(leg, np.eye(3), np.zeros(3), target, np.array([0.1, 0.2, -0.1]), np.zeros(3), np.zeros(3), kin)
+        assert np.isnan(tau).all(), tau
