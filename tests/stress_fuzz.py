@@ -44,6 +44,7 @@ def run(trials=150, n=2048, budget_s=None, min_trials=6):
             okm = (oo["status"] == 0) & (ss == 0)
             scale = np.maximum(1.0, np.abs(rr).max(axis=1, keepdims=True))
             err = float(np.max((np.abs(oo["grf_body"] - rr) / scale)[okm])) if okm.any() else 0.0
+            err = err if err == err else float("inf")  # (a NaN force of a "solved" robot must not hide behind nan > tol == False)
             mism = int(((oo["status"] == 0) != (ss == 0)).sum())
             worst = max(worst, err); bad += mism
             if err > 1e-6 or mism: print("trial", trial, tag, ctl.kernel_name, "err %.2e status mismatches %d" % (err, mism), {k: (v if np.isscalar(v) else "...") for k, v in P.items() if k in ("mu", "fzmin", "fzmax", "mass")})
@@ -53,6 +54,7 @@ def run(trials=150, n=2048, budget_s=None, min_trials=6):
             okm = (o1["status"] == 0) & (s1 == 0)
             scale = np.maximum(1.0, np.abs(r1).max(axis=1, keepdims=True))
             err = float(np.max((np.abs(o1["grf_body"] - r1) / scale)[okm])) if okm.any() else 0.0
+            err = err if err == err else float("inf")
             mism = int(((o1["status"] == 0) != (s1 == 0)).sum())
             worst = max(worst, err); bad += mism
             if err > 1e-6 or mism: print("trial", trial, "warm", ctl.kernel_name, "err %.2e status mismatches %d max iters %d" % (err, mism, o1["iterations"].max()))

@@ -40,6 +40,7 @@ def run(batches=40, n=4096, budget_s=None, min_batches=4):
         scale = np.maximum(1.0, np.abs(ref).max(axis=1, keepdims=True))
         e = (np.abs(o["grf_body"] - ref) / scale).max(axis=1)
         err = float(e[okm].max()) if okm.any() else 0.0
+        err = err if err == err else float("inf")  # (a NaN force of a "solved" robot must not hide behind nan > tol == False)
         worst = max(worst, err)
         if err > 1e-6 or (o["status"] != st).any():
             i = int(np.argmax(np.where(okm, e, 0)))
