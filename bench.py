@@ -123,14 +123,16 @@ def time_launches(launches, steps, warmup, dist=None, warm_all=False):
     w = max(warmup, min(m, 8))  # at least a few sets so that every code path is paged in
     if warm_all:  # stateful ticks: every set has seen its first call (which plans all swinging legs) before the clock starts
         w = max(w, m)
+    # (the events exist before the bracket: creating them between the synchronize and the first timed launch would only
+    # lengthen the idle gap the GPU comes out of - at the driver's 20 steps every microsecond of it is 0.25 % of the region)
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
     for i in range(w):
         launches[i % m]()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()  # torch's current stream == the stream control_batch launches on
     for i in range(steps):
