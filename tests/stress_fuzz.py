@@ -11,7 +11,7 @@ from oracle import c_oracle as O
 
 def run(trials=150, n=2048, budget_s=None, min_trials=6):
     """Returns (worst relative error over solved robots, status mismatches, trials done); stops early once budget_s is spent."""
-    rng = np.random.default_rng(77)
+    rng = np.random.default_rng(int(os.environ.get("QC_FUZZ_SEED", 77)))  # QC_FUZZ_SEED: another campaign (the default is the one pytest runs)
     worst = 0.0; bad = 0; t0 = time.time(); forms = {}
     for trial in range(trials):
         if budget_s is not None and trial >= min_trials and time.time() - t0 > budget_s: trial -= 1; break

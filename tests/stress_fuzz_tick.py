@@ -12,7 +12,7 @@ from oracle import c_oracle as O
 
 def run(batches=30, n=4096, budget_s=None, min_batches=3):
     """Returns (worst GRF error, worst torque error / tau_max, torque entries off by > 1e-6, status mismatches, batches done)."""
-    rng = np.random.default_rng(999)
+    rng = np.random.default_rng(int(os.environ.get("QC_FUZZ_SEED", 999)))  # QC_FUZZ_SEED: another campaign (the default is the one pytest runs)
     worst = 0.0; worst_f = 0.0; mism = 0; t0 = time.time(); flips = 0; nan_mismatch = 0
     for bi in range(batches):
         if budget_s is not None and bi >= min_batches and time.time() - t0 > budget_s: bi -= 1; break
