@@ -43,6 +43,7 @@ BYTES_PER_ROBOT_WARM = 496   # + 4 B warm word read + 4 B active-set word writte
 # (32 B), joint_qdot (96 B) and the 224-byte swing-planning record read, + the record's 32 B of state words (leg_state, has_traj)
 # every tick rewrites - its 192 B of trajectory end points are written only on a stance -> swing edge, which the replayed
 # bench tick does not have after its first launch.
+SWEEP_STEPS = 50  # timed steps of every other_configs entry (independent of --steps)
 BYTES_PER_ROBOT_FUSED = 584  # 384 + 4 read; 96 + 4 + 96 written
 BYTES_PER_ROBOT_FULL = 964   # 384 + 32 + 96 + 224 read; 96 + 4 + 96 + 32 written
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
@@ -628,13 +629,16 @@ def main():
         torch.cuda.empty_cache()
         if world == 1 and not args.no_sweep:
             other = {}
-            k = max(5, min(args.steps, 50))
+            # the sweep's entries do not follow --steps: fifty steps each, whatever the headline was asked for, so that an entry reads the
+            # same from a default run and from the driver's 20-step run (the barrier + synchronize bracket costs ~30 us per timed region:
+            # 1.5 us per step over 20 steps, 0.6 over 50 - DESIGN.md section 6 "Steps")
+            k = SWEEP_STEPS
             for c in (2, 3, 4):
                 if c == cfg:
                     continue
                 r = run_config(ctl, q, c, CONFIG_N[c], 0, k, 10, None, device)
                 bp = BYTES_PER_ROBOT_WARM if r["warm"] else BYTES_PER_ROBOT_COLD
-                other[f"config{c}"] = {"robots": CONFIG_N[c], "solved_fraction": r["solved_all_sets"] / (r["sets"] * CONFIG_N[c]), "sets": r["sets"],
+                other[f"config{c}"] = {"robots": CONFIG_N[c], "solved_fraction": r["solved_all_sets"] / (r["sets"] * CONFIG_N[c]), "sets": r["sets"], "steps": k,
                                        "cold_cache": rates(r, "cold", CONFIG_N[c], k, bp), "warm_cache": rates(r, "warm_cache", CONFIG_N[c], k, bp)}
                 attach_pmc(other[f"config{c}"], c, CONFIG_N[c], sha, ctl.kernel_name)
                 del r
@@ -656,7 +660,7 @@ def main():
                 r = run_config(ctl, q, c, nn, 0, k, 3, None, device, fused=fz)
                 bp = bytes_per_robot(False, fz)
                 tk = "full" if fz == "full" else "fused"
-                e = {"robots": nn, "solved_fraction": r["solved_all_sets"] / (r["sets"] * nn), "sets": r["sets"], "bytes_per_robot": bp,
+                e = {"robots": nn, "solved_fraction": r["solved_all_sets"] / (r["sets"] * nn), "sets": r["sets"], "steps": k, "bytes_per_robot": bp,
                      "ticks_per_s": nn * k / r["cold"][0],
                      "cold_cache": rates(r, "cold", nn, k, bp), "warm_cache": rates(r, "warm_cache", nn, k, bp), "what": what}
                 e["roofline"] = {"bound": "hbm", "achieved": e["cold_cache"]["hbm_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
