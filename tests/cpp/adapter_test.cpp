@@ -4,7 +4,8 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
-#include <qc_balance_controller.hpp>
+// the include line of commander_node.cpp:34, gait_visualizer_node.cpp:31 and test_node.cpp:17, resolved by -I <repo>/include
+#include <quadruped_controller/balance_controller.hpp>
 
 using namespace quadruped_controller;
 

@@ -96,8 +96,41 @@ def test_product_does_not_import_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in txt.replace("the oracle", "").replace("oracle/", "") or f in ("balance_controller.py",), f
                 assert "import oracle" not in txt and "from oracle" not in txt, f
-    for f in os.listdir(os.path.join(ROOT, "include")):
-        assert "oracle" not in open(os.path.join(ROOT, "include", f)).read()
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "include")):
+        for f in files:
+            assert "oracle" not in open(os.path.join(dirpath, f)).read(), f
+
+
+def test_forwarding_header_at_the_reference_include_path(built, tmp_path):
+    """the reference's callers spell the class `#include <quadruped_controller/balance_controller.hpp>`
+    (commander_node.cpp:34, gait_visualizer_node.cpp:31, test_node.cpp:17).  With -I <repo>/include that line must resolve to
+    the GPU-backed adapter - same namespace, class, ctor and control() - without the caller editing anything.  Compile-only
+    here (no GPU); tests/cpp/adapter_test.cpp includes the class the same way and runs on the GPU box."""
+    import subprocess
+
+    fwd = os.path.join(ROOT, "include", "quadruped_controller", "balance_controller.hpp")
+    txt = open(fwd).read()
+    assert "qc_balance_controller.hpp" in txt and "__has_include(<quadruped_controller/gait.hpp>)" in txt and "QC_USE_REFERENCE_TYPES" in txt
+    assert os.listdir(os.path.dirname(fwd)) == ["balance_controller.hpp"]  # nothing here may shadow the caller's own gait.hpp / types.hpp
+    src = tmp_path / "caller.cpp"
+    src.write_text("""
+#include <quadruped_controller/balance_controller.hpp>
+#include <quadruped_controller/balance_controller.hpp>  // idempotent
+using namespace quadruped_controller;
+ForceMap tick(const BalanceController& bc, const mat& R, const vec& v, const FootholdMap& feet)
+{ return bc.control(R, R, v, v, v, v, v, v, feet); }  // default gait_map = make_stance_gait(), balance_controller.hpp:107
+ForceMap tick(const BalanceController& bc, const mat& R, const vec& v, const FootholdMap& feet, const GaitMap& gait)
+{ return bc.control(R, R, v, v, v, v, v, v, feet, gait); }
+real_t row_major[4];
+void helpers(const mat& m, const vec& v) { copy_to_real_t(m, row_major); copy_to_real_t(v, row_major); (void)copy_from_real_t(row_major, 4); }
+#ifndef BALANCE_CONTROLLER_HPP
+#error "the reference's include guard is not defined: a second include of its own file would redefine the class"
+#endif
+""")
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src)],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "#include <quadruped_controller/balance_controller.hpp>" in open(os.path.join(ROOT, "tests", "cpp", "adapter_test.cpp")).read()
 
 
 def test_gait_rule():
