@@ -44,16 +44,34 @@ BYTES_PER_ROBOT_WARM = 496   # + 4 B warm word read + 4 B active-set word writte
 # every tick rewrites - its 192 B of trajectory end points are written only on a stance -> swing edge, which the replayed
 # bench tick does not have after its first launch.
 SWEEP_STEPS = 50  # timed steps of every other_configs entry (independent of --steps)
+SWEEP_WARMUP = 20     # warm-up launches of the tick entries ...
+# ... and the least time EVERY timed region of this file spends launching the same workload before its clock starts (on top of
+# the W warm-up steps asked for).  tools/tick_protocol_scan.py (profiles/r05_tick_protocol_*.log): after the seconds of host-side
+# input generation that precede a timed region the device needs ~10-20 ms of work to come back to its running clocks - the first
+# ~60 launches of the 262,144-robot tick take 157-167 us, then 151, then 141-145 in steady state; a 50-step region after 3 warm-up
+# launches read 158-160 us, the same launches after 25 ms of warm-up 140.5-141.7 (that was round 4's "profile says 143-148, bench
+# line says 157-160").  A controller stepping robots every tick runs on a device that is up; that is what is reported.
+SWEEP_WARM_MS = 25.0
 BYTES_PER_ROBOT_FUSED = 584  # 384 + 4 read; 96 + 4 + 96 written
-BYTES_PER_ROBOT_FULL = 964   # 384 + 32 + 96 + 224 read; 96 + 4 + 96 + 32 written
+BYTES_PER_ROBOT_FULL = 964   # 384 + 32 + 96 + 224 read; 96 + 4 + 96 + 32 written (frozen gait phase: "full-frozen")
+# the complete tick with the gait clock running: + 8 B gait_dt read + 32 B advanced phases written back, and 48 B
+# (p_start + p_final of one leg) for every stance -> swing edge, at the realised rate of the timed region
+BYTES_PER_ROBOT_CLOCK = 8 + 32
+BYTES_PER_LEG_EDGE = 48
+GAIT_DT = 1.0 / 300.0        # the controller's tick, mit_cheetah_config.yaml:3 (commander_node.cpp:343 loop rate)
+GAIT_T_SWING, GAIT_T_STANCE = 0.18, 0.8  # mit_cheetah_config.yaml:17-18 = qc_set_gait's defaults
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
 ROTATE_BYTES = 512 << 20     # the rotating sets of the cold-cache protocol cover more than this
 CONFIG5_TOTAL = 2097152
 
 CONFIG_N = {2: 4096, 3: 65536, 4: 262144, 5: 262144}  # robots per GPU (weak scaling / N = 1)
 TICK_DESC = {"fused": "; TICK: joint_q -> forward kinematics -> control() -> clamp(J^T f) -> joint_tau in the same launch (584 B/robot)",
-             "full": "; TICK: joint states + COM state + gait phases -> complete joint torque command (FK, contact rule, foothold planner, swing "
-                     "trajectories, IK, joint PD, QP, J^T) in the same launch (964 B/robot), contact states from trot phases"}
+             "full": "; TICK: joint states + COM state + gait phases + dt -> complete joint torque command (gait clock GaitScheduler::update, FK, contact "
+                     "rule, foothold planner on every stance->swing edge, swing trajectories, IK, joint PD, QP, J^T) in the same launch; the clock "
+                     "advances by dt = 1/300 s per launch, so edges and replanning occur inside the timed region at their natural rate "
+                     "(1004 B/robot + 48 B per edge)",
+             "full-frozen": "; TICK: as 'full' with the gait phase FROZEN (no gait_dt): contact rule, swing trajectories, IK, joint PD, QP, J^T are "
+                            "timed, GaitScheduler::update and FootPlanner::singleFoot are not (964 B/robot; rounds 3-4's protocol, kept for continuity)"}
 CONFIG_DESC = {
     2: "config2: batch of {n} randomised COM poses/velocities per GPU, all 4 feet in contact, mu=0.6 pyramid cone, cold start",
     3: "config3: batch of {n} per GPU, mixed 2/3/4-foot contact states from trot/walk gait schedules, cold start",
@@ -85,14 +103,17 @@ def make_batch(cfg, n, start, seed_shift=0):
     return W.config5(n, start=start, seed=seed), None
 
 
-def bytes_per_robot(warm, fused=False):
+def bytes_per_robot(warm, fused=False, edge_legs=0.0):
+    """Algorithmic bytes per robot; `edge_legs` = stance -> swing edges per robot per tick realised in the timed region."""
+    if fused == "full":
+        return BYTES_PER_ROBOT_FULL + BYTES_PER_ROBOT_CLOCK + BYTES_PER_LEG_EDGE * edge_legs
     if fused:
-        return BYTES_PER_ROBOT_FULL if fused == "full" else BYTES_PER_ROBOT_FUSED
+        return BYTES_PER_ROBOT_FULL if fused == "full-frozen" else BYTES_PER_ROBOT_FUSED
     return BYTES_PER_ROBOT_WARM if warm else BYTES_PER_ROBOT_COLD
 
 
 def rotation_sets(n, warm, fused=False):
-    per = bytes_per_robot(warm, fused) * n
+    per = int(bytes_per_robot(warm, fused)) * n
     return 1 if per > ROTATE_BYTES else ROTATE_BYTES // per + 1
 
 
@@ -106,17 +127,55 @@ def make_tick_batch(cfg, n, start, fused, j=0):
 
     batch, _ = make_batch(cfg, n, start, seed_shift=0x100 * j)
     batch = W.with_joint_angles(batch, seed=0x5EED0006 + 0x100 * j, start=start)
-    if fused == "full":
+    if fused in ("full", "full-frozen"):
         batch = W.with_swing_references(batch, seed=0x5EED0007 + 0x100 * j, start=start)
         idx = np.arange(start, start + n, dtype=np.uint64)
         phase = np.fmod(np.array([0.0, 0.5, 0.5, 0.0])[None] + W.uniform(0x5EED0009 + 0x100 * j, idx, 3)[:, None], 1.0)
         batch = {k: v for k, v in batch.items() if k not in ("stance", "swing_pos", "swing_vel")}
         batch["gait_phase"] = np.ascontiguousarray(phase)
+        if fused == "full":  # the on-device gait clock (gait.cpp:113-123): every launch is one controller tick later
+            batch["gait_dt"] = np.full(n, GAIT_DT)
     return batch
 
 
-def time_launches(launches, steps, warmup, dist=None, warm_all=False):
+def stance_from_phase(ph, duty):
+    """GaitScheduler::phase(), gait.cpp:125-134, on a torch tensor of phases (the 1e-12 slack of math::almost_equal)."""
+    return ((ph > 0.0) | (ph.abs() < 1.0e-12)) & ((ph < duty) | ((ph - duty).abs() < 1.0e-12))
+
+
+def count_gait_edges(phase0, launches_of_set, n, phase_after):
+    """What the timed region of a clocked tick did to the gait: replays GaitScheduler::update (gait.cpp:113-123, the same
+    fmod arithmetic as the device) from the phases snapshotted when the clock started, `launches_of_set[j]` times for set j,
+    counts the stance -> swing edges (each one a FootPlanner::singleFoot call + a trajectory reset on the device) and checks
+    the replayed phases against the ones the device left behind.  Returns (edges, leg-ticks, robots with an edge, robot-ticks,
+    max |replayed - device phase|)."""
+    import torch
+
+    step = 1.0 / (GAIT_T_SWING + GAIT_T_STANCE) * GAIT_DT
+    duty = GAIT_T_STANCE / (GAIT_T_SWING + GAIT_T_STANCE)
+    edges = legs = robots_edge = robots = 0
+    worst = 0.0
+    for j, c in enumerate(launches_of_set):
+        ph = phase0[j * n:(j + 1) * n].clone()
+        st = stance_from_phase(ph, duty)
+        for _ in range(c):
+            ph = torch.fmod(ph + step, 1.0)
+            st_new = stance_from_phase(ph, duty)
+            e = st & ~st_new
+            edges += int(e.sum().item())
+            robots_edge += int(e.any(dim=1).sum().item())
+            st = st_new
+        legs += 4 * n * c
+        robots += n * c
+        worst = max(worst, float((ph - phase_after[j * n:(j + 1) * n]).abs().max().item()))
+    return edges, legs, robots_edge, robots, worst
+
+
+def time_launches(launches, steps, warmup, dist=None, warm_all=False, warm_ms=0.0, before_timed=None):
     """W untimed steps, then K timed steps bracketed by barrier + synchronize; step i runs launches[i % len].
+    `warm_ms` > 0: after the W steps keep launching whole rotations (untimed) until that much wall time has passed, so that a
+    short timed region does not start on a device whose clocks are still coming up (SWEEP_WARM_MS above).
+    `before_timed(w)`: called once after the warm-up has drained (w = launches done so far), outside the timed region.
     Returns (wall seconds for K steps, HIP-event seconds for K steps)."""
     import torch
 
@@ -131,6 +190,15 @@ def time_launches(launches, steps, warmup, dist=None, warm_all=False):
     for i in range(w):
         launches[i % m]()
     torch.cuda.synchronize()
+    if warm_ms > 0.0:
+        t_w = time.perf_counter()
+        while (time.perf_counter() - t_w) * 1e3 < warm_ms:
+            for _ in range(m):
+                launches[w % m]()
+                w += 1
+            torch.cuda.synchronize()
+    if before_timed is not None:
+        before_timed(w)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -147,9 +215,10 @@ def time_launches(launches, steps, warmup, dist=None, warm_all=False):
     return wall, ev0.elapsed_time(ev1) * 1e-3
 
 
-def run_config(ctl, q, cfg, n, start, steps, warmup, dist=None, device=0, fused=False, protocols=("cold", "warm")):
+def run_config(ctl, q, cfg, n, start, steps, warmup, dist=None, device=0, fused=False, protocols=("cold", "warm"), warm_ms=0.0):
     """Runs the workload under the cold-cache protocol (rotating sets) and/or as a replay of one resident set.
-    Returns dict(cold=(wall, event_s), warm_cache=(wall, event_s), solved, n, sets, batch (host, set 0), warm)."""
+    Returns dict(cold=(wall, event_s), warm_cache=(wall, event_s), solved, n, sets, batch (host, set 0), warm) and, for the
+    clocked complete tick (fused == "full"), gait = what the gait clock did inside the cold timed region."""
     import numpy as np
     import torch
 
@@ -184,7 +253,8 @@ def run_config(ctl, q, cfg, n, start, steps, warmup, dist=None, device=0, fused=
             prevs.append(p)
         big = {k: torch.from_numpy(np.concatenate([h[k] for h in hosts])).to(dev) for k in batch}
         del hosts
-    if fused == "full":  # one planning record per robot of every set (in/out)
+    stateful = fused in ("full", "full-frozen")
+    if stateful:  # one planning record per robot of every set (in/out)
         big["swing_state"] = torch.from_numpy(q.new_swing_states(sets * n).view("uint8").reshape(-1).copy()).to(dev)
     out = {"grf_body": torch.empty((sets * n, 12), dtype=torch.float64, device=dev),
            "status": torch.empty((sets * n,), dtype=torch.int32, device=dev)}
@@ -207,9 +277,30 @@ def run_config(ctl, q, cfg, n, start, steps, warmup, dist=None, device=0, fused=
         launches.append(ctl.plan_batch(bj, warm=None if warm is None else warm[sl], out=oj)[0])
     res = dict(n=n, sets=sets, batch=batch, warm=is_warm, out={k: v[:n] for k, v in out.items()})
     if "cold" in protocols:
-        res["cold"] = time_launches(launches, steps, warmup, dist, warm_all=fused == "full")
+        snap = {}
+
+        def before_timed(w):  # the clock is about to start: remember where every robot's gait clock stands
+            snap["w"] = res["warmup_done"] = w
+            if fused == "full":
+                snap["phase"] = big["gait_phase"].clone()
+
+        res["cold"] = time_launches(launches, steps, warmup, dist, warm_all=stateful, warm_ms=warm_ms, before_timed=before_timed)
+        if fused == "full":
+            per_set = [sum(1 for i in range(steps) if (snap["w"] + i) % sets == j) for j in range(sets)]
+            edges, legs, r_edge, r_ticks, worst = count_gait_edges(snap["phase"], per_set, n, big["gait_phase"])
+            res["gait"] = {"dt_s": GAIT_DT, "period_s": GAIT_T_SWING + GAIT_T_STANCE, "timed_ticks_per_set": per_set,
+                           "stance_to_swing_edges": edges, "edge_legs_per_robot_tick": edges / r_ticks,
+                           "robots_replanning_per_tick": r_edge / r_ticks,
+                           "expected_edge_legs_per_robot_tick": 4.0 * GAIT_DT / (GAIT_T_SWING + GAIT_T_STANCE),
+                           "device_phase_vs_replayed_clock_max_abs": worst,
+                           "what": "GaitScheduler::update (gait.cpp:113-123) runs on the device at the start of every robot's tick: each launch "
+                                   "is one controller tick (dt = 1/300 s) later; a stance -> swing edge makes that leg replan its foothold "
+                                   "(FootPlanner::singleFoot, foot_planner.cpp:76-157) and resets the trajectories (trajectory.cpp:308-344) - "
+                                   "counted by replaying the clock on the snapshot taken when the timed region started and checked against the "
+                                   "phases the device left behind (0 = bit-equal)"}
+            del snap["phase"]
     if "warm" in protocols:
-        res["warm_cache"] = time_launches(launches[:1], steps, warmup, dist)
+        res["warm_cache"] = time_launches(launches[:1], steps, warmup, dist, warm_ms=warm_ms)
     res["solved"] = int((out["status"][:n] == 0).sum().item())
     res["solved_all_sets"] = int((out["status"] == 0).sum().item()) if "cold" in protocols else res["solved"]
     return res
@@ -309,6 +400,49 @@ def cpu_baseline(P, batch, budget_s=4.0):
             "refinement": "off (the checker's long-double recomputation of the accepted point is not timed; decisions are the same)"}
 
 
+def cpu_baseline_tick(P, batch, budget_s=2.5):
+    """The C oracle's complete tick (oracle_gait_update + oracle_tick_planned_batch: gait clock, FK, contact rule, foothold
+    planner, swing trajectories, IK, joint PD, QP, J^T - the restatement of commander_node.cpp:383-531) on the host cores over
+    robots of the same workload, the clock advancing by 1/300 s per call like the timed launches."""
+    from oracle import c_oracle
+
+    import numpy as np
+
+    threads = host_cores()
+    base = min(batch["x"].shape[0], 4096)
+    tile = max(1, (256 * threads + base - 1) // base)
+    keys = ("Rwb", "Rwb_d", "x", "xdot", "w", "x_d", "xdot_d", "w_d", "joint_q", "joint_qdot", "gait_phase")
+    sample = {k: np.ascontiguousarray(np.tile(batch[k][:base], (tile, 1))) for k in keys}
+    n = base * tile
+    dt = np.full(n, GAIT_DT)
+    kin = c_oracle.default_kinematics()
+    kin.t_swing, kin.t_stance = GAIT_T_SWING, GAIT_T_STANCE
+    states = c_oracle.new_swing_states(n)
+    c_oracle.set_refine(False)
+    try:
+        c_oracle.tick_planned_batch(P, sample, states, kin=kin, threads=threads)  # the first call plans every swinging leg: not timed, as on the GPU
+        one_b = {k: v[:256].copy() for k, v in sample.items()}
+        one_s = states[:256].copy()
+        t0 = time.perf_counter()
+        c_oracle.gait_update(one_b["gait_phase"], dt[:256], kin=kin)
+        c_oracle.tick_planned_batch(P, one_b, one_s, kin=kin, threads=1)
+        one = 256 / (time.perf_counter() - t0)
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            c_oracle.gait_update(sample["gait_phase"], dt, kin=kin)
+            c_oracle.tick_planned_batch(P, sample, states, kin=kin, threads=threads)
+            reps += 1
+            if time.perf_counter() - t0 >= budget_s:
+                break
+        wall = time.perf_counter() - t0
+    finally:
+        c_oracle.set_refine(True)
+    return {"value": reps * n / wall, "unit": "robot ticks/s", "cores": threads, "kind": "port",
+            "sample": f"first {base} robots of the entry's set 0 tiled x{tile} = {n} robots per call x {reps} consecutive ticks (dt = 1/300 s), {threads} "
+                      f"OpenMP threads, {wall:.1f} s wall; C restatement of the reference's tick, not the reference binary",
+            "single_thread_value": one, "cpu_model": cpu_model(), "threads": threads, "compiler": oracle_build_flags()}
+
+
 def batch_load_probe(q, P, device, nb=2097152, steps=10):
     """north_star: "achieved HBM GB/s on the batch load".  Same kernel with the solver iterations skipped
     (qc_set_tuning "probe_batch_load": load -> PD law / rotation log / Newton-Euler rhs -> output transform -> store;
@@ -323,7 +457,7 @@ def batch_load_probe(q, P, device, nb=2097152, steps=10):
     batch = {k: v.repeat(8, 1).contiguous() for k, v in base.items()}
     out = {"grf_body": torch.empty((nb, 12), dtype=torch.float64, device=f"cuda:{device}"),
            "status": torch.empty((nb,), dtype=torch.int32, device=f"cuda:{device}")}
-    _, evs = time_launches([probe.plan_batch(batch, out=out)[0]], steps, 2)
+    _, evs = time_launches([probe.plan_batch(batch, out=out)[0]], steps, 2, warm_ms=SWEEP_WARM_MS)
     gbs = BYTES_PER_ROBOT_COLD * nb * steps / evs / 1e9
     return {"robots": nb, "bytes": BYTES_PER_ROBOT_COLD * nb, "us": evs / steps * 1e6, "achieved": gbs, "unit": "GB/s",
             "peak": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS,
@@ -394,10 +528,12 @@ def pmc_traffic(cfg, n, sha, kernel, tick=None):
     return best
 
 
-def attach_pmc(target, cfg, n, sha, kernel, tick=None):
+def attach_pmc(target, cfg, n, sha, kernel, tick=None, kernel_us=None):
     """roofline.traffic / roofline_valu of `target` (a bench line or an other_configs entry) from the committed,
     hash-matched PMC pass of that workload.  The HBM fraction is what the contract asks for; the bound that binds the
-    solve is FP64 VALU issue, so that one travels next to it."""
+    solve is FP64 VALU issue, so that one travels next to it.  `kernel_us` = the average kernel time THIS run measured for
+    the entry: the issue fraction is the profile's instruction count over this run's time (the profile's own
+    kernel time described another run)."""
     tr = pmc_traffic(cfg, n, sha, kernel, tick)
     if tr is None:
         return
@@ -409,9 +545,15 @@ def attach_pmc(target, cfg, n, sha, kernel, tick=None):
         target["hbm_traffic_bytes_per_launch"] = tr[0]
     if tr[2]:
         v = tr[2]
+        own = kernel_us is not None and kernel_us > 0.0
+        frac = v["insts_valu_per_launch"] * 4.0 / (1024.0 * kernel_us * 1e3 * 2.4) if own else v["issue_frac"]
         target["roofline_valu"] = {"bound": "fp64-valu-issue", "insts_valu_per_launch": v["insts_valu_per_launch"],
-                                   "insts_valu_per_robot": v["insts_valu_per_robot"], "issue_frac": v["issue_frac"],
-                                   "how": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x kernel time x 2.4 GHz), kernel time of the profiled run",
+                                   "insts_valu_per_robot": v["insts_valu_per_robot"], "issue_frac": frac,
+                                   "kernel_us": kernel_us if own else v.get("kernel_ns", 0.0) * 1e-3,
+                                   "issue_frac_of_profiled_run": v["issue_frac"],
+                                   "how": "SQ_INSTS_VALU (committed PMC pass, an instruction count: the same in every run of these kernels on this "
+                                          "workload) x 4 cycles / (1024 SIMDs x kernel time x 2.4 GHz), kernel time = "
+                                          + ("this entry's own HIP-event average" if own else "the profiled run's"),
                                    "source": src}
 
 
@@ -449,10 +591,14 @@ def main():
     ap.add_argument("--probe-batch-load", action="store_true",
                     help="time the load -> assemble -> store phase alone (no solver iterations) on 2,097,152 robots "
                          "(done by default together with the sweep)")
-    ap.add_argument("--tick", choices=["fused", "full"], default=None,
+    ap.add_argument("--tick", choices=["fused", "full", "full-frozen"], default=None,
                     help="development / profiling: time the SURVEY 8(f) tick built around the QP instead of the QP alone - fused = joint_q -> "
-                         "FK -> control() -> J^T -> joint_tau; full = + contact rule, foothold planner, swing trajectories, IK, joint PD")
+                         "FK -> control() -> J^T -> joint_tau; full = + gait clock (dt = 1/300 s per launch), contact rule, foothold planner on every "
+                         "stance->swing edge, swing trajectories, IK, joint PD; full-frozen = full without gait_dt (the phases never move)")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="development: qc_set_tuning override(s)")
+    ap.add_argument("--device-warm-ms", type=float, default=SWEEP_WARM_MS,
+                    help="besides the W warm-up steps, keep launching the workload (untimed) for this many milliseconds before the timed region, "
+                         "so that it starts on a device at its running clocks (0: exactly W warm-up steps, the device possibly still ramping up)")
     args = ap.parse_args()
 
     one_dev = os.environ.get("QC_BENCH_ONE_DEVICE") == "1"  # test hook: all ranks on cuda:0, gloo instead of RCCL
@@ -534,8 +680,8 @@ def main():
             return shard_bounds(total, r, world)
         return r * n, (r + 1) * n
 
-    fused = {None: False, "fused": True, "full": "full"}[args.tick]
-    res = run_config(ctl, q, cfg, n, start, args.steps, args.warmup, dist, device, fused=fused)
+    fused = {None: False, "fused": True, "full": "full", "full-frozen": "full-frozen"}[args.tick]
+    res = run_config(ctl, q, cfg, n, start, args.steps, args.warmup, dist, device, fused=fused, warm_ms=args.device_warm_ms)
 
     from quadruped_control_amd.sharding import reduce_counters
 
@@ -557,7 +703,7 @@ def main():
 
     if rank == 0:
         sha = kernel_src_sha16()
-        bytes_per = bytes_per_robot(res["warm"], fused)
+        bytes_per = bytes_per_robot(res["warm"], fused, res.get("gait", {}).get("edge_legs_per_robot_tick", 0.0))
         kernel_s = res["cold"][1] / args.steps
         achieved = bytes_per * n / kernel_s / 1e9
         info = ctl.query_launch(n, kin=bool(fused), warm=res["warm"])
@@ -583,6 +729,11 @@ def main():
                        "cache_protocol": f"cold: the timed loop rotates through {res['sets']} distinct input/output sets "
                                          f"({res['sets'] * bytes_per * n / 2**20:.0f} MiB in total) so every launch reads its inputs from HBM"},
             "solved_fraction": solved_total / total_robots,
+            "device_warmup": {"ms": args.device_warm_ms, "warmup_launches_done": res.get("warmup_done"),
+                              "what": "untimed launches of the same workload before the K timed steps: the W asked for, at least one per rotating set "
+                                      "(capped at 8), then until `ms` of wall time have passed - after the host-side input generation the device "
+                                      "needs 10-20 ms of work to be back at its running clocks (profiles/r05_tick_protocol_*.log); "
+                                      "`--device-warm-ms 0` times the ramp instead"},
             "kernel_src_sha16": sha,
             "warm_cache": {"value": total_robots * args.steps / wall_warm, "ms_per_step": wall_warm / args.steps * 1e3,
                            "avg_kernel_us": res["warm_cache"][1] / args.steps * 1e6,
@@ -602,7 +753,11 @@ def main():
         if gather_s is not None:
             line["result_gather"] = {"bytes_per_rank": n * 96, "seconds": gather_s, "GBs_per_rank": n * 96 * (world - 1) / gather_s / 1e9,
                                      "what": "all-gather of the [n, 12] GRF blocks after the timed region (not part of value)"}
-        attach_pmc(line, cfg, n, sha, ctl.kernel_name, tick=args.tick)
+        attach_pmc(line, cfg, n, sha, ctl.kernel_name, tick=args.tick, kernel_us=kernel_s * 1e6)
+        if "gait" in res:
+            line["gait_clock"] = res["gait"]
+            line["roofline"]["bytes_per_robot"] = (f"{bytes_per:.2f} = 964 (frozen-phase tick) + 8 gait_dt read + 32 advanced phases written + 48 x "
+                                                   f"{res['gait']['edge_legs_per_robot_tick']:.5f} stance->swing edges per robot per tick")
         if dist is not None:
             line["ranks"] = {"avg_kernel_us_min": k_min, "avg_kernel_us_max": k_max,
                              "allreduce_us": allreduce_s * 1e6, "backend": dist.get_backend(),
@@ -613,7 +768,7 @@ def main():
             # ranks wait at the final barrier: the WHOLE batch on one device, so that the line explains itself
             del res
             torch.cuda.empty_cache()
-            r1 = run_config(ctl, q, cfg, total_robots, 0, 10, 10, None, device, protocols=("cold",))
+            r1 = run_config(ctl, q, cfg, total_robots, 0, 10, 10, None, device, protocols=("cold",), warm_ms=args.device_warm_ms)
             line["n1_reference"] = {"robots": total_robots, "value": total_robots * 10 / r1["cold"][0], "avg_kernel_us": r1["cold"][1] / 10 * 1e6,
                                     "solved_fraction": r1["solved"] / total_robots,
                                     "what": "the whole batch on rank 0's GPU alone, after the timed region (not part of value)"}
@@ -636,29 +791,39 @@ def main():
             for c in (2, 3, 4):
                 if c == cfg:
                     continue
-                r = run_config(ctl, q, c, CONFIG_N[c], 0, k, 10, None, device)
+                r = run_config(ctl, q, c, CONFIG_N[c], 0, k, 10, None, device, warm_ms=args.device_warm_ms)
                 bp = BYTES_PER_ROBOT_WARM if r["warm"] else BYTES_PER_ROBOT_COLD
                 other[f"config{c}"] = {"robots": CONFIG_N[c], "solved_fraction": r["solved_all_sets"] / (r["sets"] * CONFIG_N[c]), "sets": r["sets"], "steps": k,
                                        "cold_cache": rates(r, "cold", CONFIG_N[c], k, bp), "warm_cache": rates(r, "warm_cache", CONFIG_N[c], k, bp)}
-                attach_pmc(other[f"config{c}"], c, CONFIG_N[c], sha, ctl.kernel_name)
+                attach_pmc(other[f"config{c}"], c, CONFIG_N[c], sha, ctl.kernel_name, kernel_us=other[f"config{c}"]["cold_cache"]["avg_kernel_us"])
                 del r
                 torch.cuda.empty_cache()
             # the N = 1 point of the config-5 scaling curve: the full 2,097,152-robot batch on this GPU (1 GB: cold by size)
-            r = run_config(ctl, q, 5, CONFIG5_TOTAL, 0, 10, 10, None, device, protocols=("cold",))
+            r = run_config(ctl, q, 5, CONFIG5_TOTAL, 0, 10, 10, None, device, protocols=("cold",), warm_ms=args.device_warm_ms)
             other["config5_n1"] = {"robots": CONFIG5_TOTAL, "solved_fraction": r["solved"] / CONFIG5_TOTAL,
                                    "cold_cache": rates(r, "cold", CONFIG5_TOTAL, 10, BYTES_PER_ROBOT_COLD),
                                    "what": "N = 1 point of the strong-scaling curve that `bench.py --gpus N` (N > 1) continues"}
-            attach_pmc(other["config5_n1"], 5, CONFIG5_TOTAL, sha, ctl.kernel_name)
+            attach_pmc(other["config5_n1"], 5, CONFIG5_TOTAL, sha, ctl.kernel_name, kernel_us=other["config5_n1"]["cold_cache"]["avg_kernel_us"])
+            # WHICH number of this line is the N = 1 point of the 1/2/4/8 curve (`value` above is configs[1], 4096 robots)
+            line["scaling_n1"] = {"workload": "config5", "robots": CONFIG5_TOTAL, "value": other["config5_n1"]["cold_cache"]["QPs_per_s"], "unit": "QPs/s",
+                                  "avg_kernel_us": other["config5_n1"]["cold_cache"]["avg_kernel_us"],
+                                  "what": "BASELINE.json configs[4] on ONE GPU: the whole 2,097,152-robot batch.  `bench.py --gpus N` (N > 1) shards exactly "
+                                          "this batch (strong scaling), so a 1/2/4/8 curve starts HERE, not at this line's `value`"}
             del r
             torch.cuda.empty_cache()
             # the ticks built around the QP, under the same cold-cache protocol as the hot path
             for key, c, nn, fz, what in (
                     ("config2_fused_tick", 2, CONFIG_N[2], True, "joint_q -> forward kinematics -> control() -> clamp(J^T f) -> joint_tau in one launch"),
-                    ("config3_full_tick", 3, CONFIG_N[3], "full", "joint states + COM state + gait phases -> complete joint torque command "
-                     "(FK, contact rule, foothold planner, swing trajectories, IK, joint PD, QP, J^T) in one launch"),
+                    ("config3_full_tick", 3, CONFIG_N[3], "full", "joint states + COM state + gait phases + dt -> complete joint torque command "
+                     "(gait clock, FK, contact rule, foothold planner on stance->swing edges, swing trajectories, IK, joint PD, QP, J^T) in one launch; "
+                     "every launch is one controller tick (1/300 s) later"),
                     ("full_tick_262144", 3, 262144, "full", "the same complete tick on 262,144 robots (two rounds of workgroups)")):
-                r = run_config(ctl, q, c, nn, 0, k, 3, None, device, fused=fz)
-                bp = bytes_per_robot(False, fz)
+                # one protocol for the sweep entry and for the profiled run of the same workload (tools/profile_r.sh -> `bench.py --tick
+                # full --steps 50 --warmup 20`): >= 20 warm-up launches AND >= SWEEP_WARM_MS of GPU work before the clock starts - the
+                # entry used to start 3 launches (0.5 ms) after seconds of host-side input generation, on a device still ramping up
+                r = run_config(ctl, q, c, nn, 0, k, SWEEP_WARMUP, None, device, fused=fz, warm_ms=args.device_warm_ms)
+                gait = r.get("gait")
+                bp = bytes_per_robot(False, fz, gait["edge_legs_per_robot_tick"] if gait else 0.0)
                 tk = "full" if fz == "full" else "fused"
                 e = {"robots": nn, "solved_fraction": r["solved_all_sets"] / (r["sets"] * nn), "sets": r["sets"], "steps": k, "bytes_per_robot": bp,
                      "ticks_per_s": nn * k / r["cold"][0],
@@ -666,7 +831,18 @@ def main():
                 e["roofline"] = {"bound": "hbm", "achieved": e["cold_cache"]["hbm_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": e["cold_cache"]["hbm_GBs"] / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": bp * nn,
                                  "avg_kernel_us": e["cold_cache"]["avg_kernel_us"]}
-                attach_pmc(e, c, nn, sha, ctl.kernel_name, tick=tk)
+                attach_pmc(e, c, nn, sha, ctl.kernel_name, tick=tk, kernel_us=e["cold_cache"]["avg_kernel_us"])
+                if gait:
+                    e["gait_clock"] = gait
+                    if not args.no_cpu_baseline:
+                        e["cpu_baseline"] = cpu_baseline_tick(P, r["batch"])
+                    del r
+                    torch.cuda.empty_cache()
+                    # rounds 3-4's protocol next to it, for continuity: the same tick with the gait phase frozen (no gait_dt)
+                    r = run_config(ctl, q, c, nn, 0, k, SWEEP_WARMUP, None, device, fused="full-frozen", protocols=("cold",), warm_ms=args.device_warm_ms)
+                    e["frozen_phase"] = {"bytes_per_robot": BYTES_PER_ROBOT_FULL, "cold_cache": rates(r, "cold", nn, k, BYTES_PER_ROBOT_FULL),
+                                         "what": "no gait_dt: the phases never move, so GaitScheduler::update and FootPlanner::singleFoot are outside "
+                                                 "the timed region (what rounds 3 and 4 reported as the complete tick)"}
                 other[key] = e
                 del r
                 torch.cuda.empty_cache()

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define QC_ABI_VERSION 5
+#define QC_ABI_VERSION 6
 
 /* Replaces the constructor arguments of BalanceController
  * (balance_controller.hpp:85-88; defaults in commander_node.cpp:289-334 and
@@ -160,8 +160,17 @@ typedef struct qc_handle qc_handle;
 /* BalanceController::BalanceController (balance_controller.cpp:70-96).
  * `device` = HIP device ordinal.  A handle is used by one thread at a time
  * (like the reference object, whose control() mutates `mutable` members,
- * balance_controller.hpp:161-176); distinct handles are independent. */
-int qc_create(const qc_params* params, int device, qc_handle** out);
+ * balance_controller.hpp:161-176); distinct handles are independent.
+ *
+ * ABI v6: the EXPORTED constructor is qc_create_abi, which also takes the caller's view of this header (QC_ABI_VERSION and
+ * the sizes of the three structs that cross the boundary) and refuses a mismatch with QC_ERR_ABI before anything is read -
+ * qc_batch_in has grown with every revision and carries no size field, so a caller built against an older header would
+ * otherwise have its struct read past the end.  qc_create is the inline wrapper below: C and C++ callers keep writing
+ * qc_create(&params, device, &handle) and cannot skip the guard; the library no longer exports a symbol of that name, so a
+ * binary built against ABI <= 5 fails to link / load instead of running.  Bindings without a C compiler (ctypes, cgo, JNI)
+ * call qc_create_abi with the sizes of THEIR mirror structs. */
+int qc_create_abi(const qc_params* params, int device, qc_handle** out, int abi_version, size_t sizeof_params,
+                  size_t sizeof_batch_in, size_t sizeof_batch_out);
 void qc_destroy(qc_handle* h);
 
 /* control() for n robots, device-resident inputs/outputs, asynchronous on
@@ -209,7 +218,8 @@ int qc_abi_version(void);
  * sizeof(qc_batch_in) and sizeof(qc_batch_out) as the CALLER's header defines them; anything but QC_OK (QC_ERR_ABI, with
  * the two sides spelled out in qc_last_error) means the structs this library reads are not the ones the caller fills
  * (qc_batch_in has grown with every revision and carries no size field) and no other entry point may be used.  The
- * C++ adapter's constructor and the Python loader call it; qc_create does not need a device for it.
+ * C++ adapter's constructor and the Python loader call it (it needs no device); since ABI v6 the constructor performs the
+ * same check itself (qc_create_abi), so this entry point is a convenience for an early, device-free diagnosis.
  * (The reference's constructor contract, balance_controller.hpp:85-88, has no analogue: it is header-only C++.) */
 int qc_check_abi(int abi_version, size_t sizeof_params, size_t sizeof_batch_in, size_t sizeof_batch_out);
 #define QC_CHECK_ABI() qc_check_abi(QC_ABI_VERSION, sizeof(qc_params), sizeof(qc_batch_in), sizeof(qc_batch_out))
@@ -256,4 +266,9 @@ int qc_set_tuning(qc_handle* h, const char* key, double value);
 #ifdef __cplusplus
 }
 #endif
+
+/* The constructor every C / C++ caller uses (see qc_create_abi above): the ABI guard travels with it. */
+static inline int qc_create(const qc_params* params, int device, qc_handle** out) {
+  return qc_create_abi(params, device, out, QC_ABI_VERSION, sizeof(qc_params), sizeof(qc_batch_in), sizeof(qc_batch_out));
+}
 #endif /* QC_BALANCE_H */

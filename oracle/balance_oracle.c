@@ -587,7 +587,7 @@ void oracle_leg_ik(const oracle_kinematics* k, int leg, const double* foothold, 
  * (Hestenes): columns of A = J V are rotated pairwise until orthogonal, then sigma_i = |a_i|, u_i = a_i / sigma_i,
  * which keeps tiny singular values accurate (nothing is squared).  pinv = sum over sigma_i > tol of v_i u_i^T / sigma_i.
  * Returns 0 if the sweeps do not converge (never observed; the caller then falls through to J^T as the reference does). */
-int oracle_pinv3(const double* J, double* Jp) {
+static int pinv3_keep(const double* J, int keep, double* Jp) {
   double A[3][3], V[3][3];
   for (int i = 0; i < 3; i++)
     for (int j = 0; j < 3; j++) { A[i][j] = J[3 * i + j]; V[i][j] = (i == j) ? 1.0 : 0.0; }
@@ -634,13 +634,56 @@ int oracle_pinv3(const double* J, double* Jp) {
   }
   const double tol = 3.0 * smax * 2.220446049250313e-16;
   for (int i = 0; i < 9; i++) Jp[i] = 0.0;
-  for (int j = 0; j < 3; j++) {
+  /* keep <= 3 (oracle_pinv3): Armadillo's tolerance decides alone.  keep < 3 (oracle_pinv3_band): at most the `keep` largest
+   * singular values survive, whatever their size. */
+  int order[3] = {0, 1, 2};
+  for (int a = 0; a < 2; a++)
+    for (int b = a + 1; b < 3; b++)
+      if (sig[order[b]] > sig[order[a]]) { const int t = order[a]; order[a] = order[b]; order[b] = t; }
+  for (int m = 0; m < 3 && m < keep; m++) {
+    const int j = order[m];
     if (!(sig[j] > tol)) continue;
     for (int r = 0; r < 3; r++)
       for (int c = 0; c < 3; c++) Jp[3 * r + c] += V[r][j] * A[c][j] / (sig[j] * sig[j]); /* v_j u_j^T / sigma_j, u_j = a_j / sigma_j */
   }
   return 1;
 }
+
+int oracle_pinv3(const double* J, double* Jp) { return pinv3_keep(J, 3, Jp); }
+
+/* Numerical rank the way this build decides it INSIDE the band where it answers with the pseudo-inverse (see
+ * oracle_swing_torque): elimination with complete pivoting, a second pivot below 1e-9 of the first counts as zero and a
+ * third pivot is never taken - in that band |det| < 64 epsilon (sum |l|)^3, so the third direction is the one that has
+ * collapsed (a stretched knee, the lateral clamp) and 1 / sigma_3 would be a 1e13 ... 1e17-sized, noise-signed gain.
+ * Armadillo's own tolerance (3 sigma_max epsilon) would keep sigma_3 for |det| between ~1e-17 and the band's upper end; the
+ * granularity of the knee cosine (|det| jumps from rounding noise to ~3e-10 one ulp below d = 1) makes that window all but
+ * unreachable, but device and checker must not depend on that: both take the rank from THIS rule (ADVICE r4;
+ * qc_device.hpp pinv3_apply is the same elimination). */
+int oracle_cp_rank3(const double* J) {
+  double A[9];
+  for (int i = 0; i < 9; i++) A[i] = J[i];
+  double piv1 = 0.0;
+  int rank = 0;
+  for (int k = 0; k < 2; k++) {
+    double best = -1.0;
+    int bi = 0, bj = 0;
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++)
+        if (fabs(A[3 * i + j]) > best) { best = fabs(A[3 * i + j]); bi = i; bj = j; }
+    if (k == 0) piv1 = best;
+    if (!(k == 0 ? best > 0.0 : (rank == 1 && best > 1.0e-9 * piv1))) break;
+    double col[3], row[3];
+    for (int i = 0; i < 3; i++) { col[i] = A[3 * i + bj]; row[i] = A[3 * bi + i]; }
+    const double ip = 1.0 / col[bi];
+    for (int i = 0; i < 3; i++) row[i] *= ip;
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) A[3 * i + j] -= col[i] * row[j];
+    rank = k + 1;
+  }
+  return rank;
+}
+
+int oracle_pinv3_band(const double* J, double* Jp) { return pinv3_keep(J, oracle_cp_rank3(J), Jp); }
 
 void oracle_swing_torque(const oracle_kinematics* k, int leg, const double* Rwb, const double* x, const double* pos,
                          const double* vel, const double* q, const double* qdot, double* tau) {
@@ -688,7 +731,7 @@ void oracle_swing_torque(const oracle_kinematics* k, int leg, const double* Rwb,
     if (!singular) {
       for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++) Jinv[3 * i + j] = M[i][3 + j];
-    } else if (!oracle_pinv3(J, Jinv)) {
+    } else if (!oracle_pinv3_band(J, Jinv)) { /* (the rank by this build's rule, the values by the SVD: see oracle_cp_rank3) */
       for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++) Jinv[3 * i + j] = J[3 * j + i]; /* :198 */
     }

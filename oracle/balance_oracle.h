@@ -101,6 +101,10 @@ void oracle_leg_ik(const oracle_kinematics* k, int leg, const double* p3, double
 /* arma::pinv of a 3x3, the fallback of legJacobianInverse (kinematics.cpp:196): SVD (one-sided Jacobi) with
  * Armadillo's default tolerance 3 * sigma_max * epsilon; Jp9 row-major.  Returns 0 if the SVD did not converge. */
 int oracle_pinv3(const double* J9, double* Jp9);
+/* the pseudo-inverse of the band where this build answers with pinv: rank by complete pivoting (at most 2, second pivot > 1e-9
+ * of the first - the device's rule, qc_device.hpp pinv3_apply), values from the SVD truncated to that rank */
+int oracle_cp_rank3(const double* J9);
+int oracle_pinv3_band(const double* J9, double* Jp9);
 /* Swing-leg torque of one leg as commander_node.cpp:482-504 + joint_controller.cpp:21-39 compute it (unclamped):
  * pos/vel = world-frame reference foot state, q/qdot = measured joint state of the leg. */
 void oracle_swing_torque(const oracle_kinematics* k, int leg, const double* Rwb, const double* x, const double* pos,

@@ -165,6 +165,17 @@ def pinv3(J):
     return out.reshape(3, 3), bool(ok)
 
 
+def pinv3_band(J):
+    """oracle_pinv3_band: what oracle_swing_torque uses inside the band where this build answers with pinv - the rank by the
+    device's complete-pivoting rule (at most 2), the values from the SVD truncated to it.  Returns (pinv, rank)."""
+    J = np.ascontiguousarray(J, np.float64).reshape(9); out = np.zeros(9)
+    lib().oracle_pinv3_band.restype = C.c_int
+    lib().oracle_cp_rank3.restype = C.c_int
+    ok = lib().oracle_pinv3_band(_dp(J), _dp(out))
+    assert ok
+    return out.reshape(3, 3), int(lib().oracle_cp_rank3(_dp(J)))
+
+
 def swing_torque(leg, Rwb, x, pos, vel, q, qdot, kin=None):
     """oracle_swing_torque of one leg (unclamped)."""
     kin = kin or default_kinematics()

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("QC_LIB_PATH") or os.path.join(_HERE, "libqc_balance.s
 
 QC_OK = 0
 QC_ERR_ABI = -4
-ABI_VERSION = 5  # the revision of include/qc_balance.h these ctypes structures were written against
+ABI_VERSION = 6  # the revision of include/qc_balance.h these ctypes structures were written against
 STATUS_NAMES = {0: "solved", 1: "max_iter", 2: "infeasible", 3: "not_pd"}
 
 
@@ -51,7 +51,7 @@ class QcLaunchInfo(C.Structure):
                 ("chunk", C.c_int64), ("blocks", C.c_int64), ("resident_workgroups", C.c_int64), ("lds_bytes", C.c_int64)]
 
 
-EXPORTS = ("qc_create", "qc_destroy", "qc_control_batch", "qc_control_batch_host", "qc_control",
+EXPORTS = ("qc_create_abi", "qc_destroy", "qc_control_batch", "qc_control_batch_host", "qc_control",
            "qc_last_error", "qc_kernel_name", "qc_abi_version", "qc_default_kinematics", "qc_set_kinematics", "qc_set_gait", "qc_swing_state_init",
            "qc_set_tuning", "qc_query_launch", "qc_check_abi")
 
@@ -82,8 +82,9 @@ def load():
     for name in EXPORTS:
         if not hasattr(lib, name):
             raise ImportError(f"{LIB_PATH} does not export {name}")
-    lib.qc_create.argtypes = [C.POINTER(QcParams), C.c_int, C.POINTER(C.c_void_p)]
-    lib.qc_create.restype = C.c_int
+    # (ABI v6: the exported constructor takes the caller's ABI revision and struct sizes; `qc_create` is an inline wrapper in the header)
+    lib.qc_create_abi.argtypes = [C.POINTER(QcParams), C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_size_t, C.c_size_t, C.c_size_t]
+    lib.qc_create_abi.restype = C.c_int
     lib.qc_destroy.argtypes = [C.c_void_p]
     lib.qc_destroy.restype = None
     lib.qc_control_batch.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(QcBatchIn), C.c_void_p,
@@ -119,6 +120,11 @@ def load():
         raise ImportError(f"{LIB_PATH}: {lib.qc_last_error().decode()}")
     _lib = lib
     return lib
+
+
+def create(lib, params, device, handle):
+    """qc_create for this binding: qc_create_abi with the revision and the sizes of the ctypes mirrors above."""
+    return lib.qc_create_abi(C.byref(params), int(device), C.byref(handle), ABI_VERSION, C.sizeof(QcParams), C.sizeof(QcBatchIn), C.sizeof(QcBatchOut))
 
 
 def last_error():

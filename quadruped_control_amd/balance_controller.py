@@ -53,7 +53,7 @@ class BalanceController:
         self._one = None  # control(): single-robot record buffers
         self._h = C.c_void_p()
         self._lib = lib
-        rc = lib.qc_create(C.byref(p), self.device, C.byref(self._h))
+        rc = _lib.create(lib, p, self.device, self._h)
         if rc != _lib.QC_OK:
             raise RuntimeError(f"qc_create failed ({rc}): {_lib.last_error()}")
 

@@ -1884,9 +1884,12 @@ int qc_set_gait(qc_handle* h, double t_swing, double t_stance) {
   return upload_params(h);
 }
 
-int qc_create(const qc_params* p, int device, qc_handle** out) {
+int qc_create_abi(const qc_params* p, int device, qc_handle** out, int abi_version, size_t sizeof_params, size_t sizeof_batch_in,
+                  size_t sizeof_batch_out) {
   if (!p || !out) return fail(QC_ERR_INVALID, "qc_create: null argument");
   *out = nullptr;
+  // ABI v6: no handle for a caller that fills other structs than this library reads (include/qc_balance.h, qc_create)
+  if (const int rc = qc_check_abi(abi_version, sizeof_params, sizeof_batch_in, sizeof_batch_out); rc != QC_OK) return rc;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(QC_ERR_NO_DEVICE, "qc_create: no HIP device visible (this library has no CPU path)");

@@ -566,6 +566,13 @@ QC_DEV void swing_pd(CParams& P, const LegGeom& g, const LegTrig& t, const doubl
   // The lower end is raised to the rounding noise of det itself, 64 epsilon (sum |l|)^3, where that is larger (legs longer
   // than ~0.4 m): below it the sign of det - and with it the sign of a saturated torque - is noise on any implementation.
   // Rounds 2-3 switched at |det| <= 1e-9 (sum |l|)^3, five orders of magnitude earlier than the reference stops inverting.
+  // Inside the pinv band the RANK is pinv3_apply's: never a third pivot, a second one only above 1e-9 of the first.  Armadillo's
+  // pinv tolerance (3 sigma_max epsilon) would keep sigma_3 for |det| between ~1e-17 and `lo` and return a 1e13 ... 1e17-sized,
+  // noise-signed gain there; IK cannot normally produce such a J (the knee cosine d takes no value between 1 - 2^-53, |det| ~ 3e-10,
+  // and 1, |det| ~ 1e-18; only two coinciding granules - sqrt(1 - d^2) ~ 1e-8 times rt ~ 1e-9 - land inside), and the checker does
+  // not rely on that: its band pseudo-inverse takes its rank from the same elimination (the CPU test
+  // test_pinv_band_takes_its_rank_from_the_device_rule).  The upper end of the band (|det| > 1 / epsilon) needs
+  // (sum |l|)^3 > 4.5e15, links of 1e5 m: the same rule applies there and nothing physical reaches it.
   const double ad = fabs(det), lsum = fabs(L1) + fabs(L2) + fabs(L3);
   const double lo = fmax(2.220446049250313e-16, 1.4210854715202004e-14 * lsum * lsum * lsum);
   double qd[3];
@@ -614,7 +621,10 @@ QC_DEV void leg_swing_torque(CParams& P, const LegGeom& g, const double (&pb)[3]
   const double rho2 = y * y + z * z;
   const double rt2 = sc;  // rt^2
   const double sig2 = x * x + rt2;
-  const bool finite = (__builtin_fma(x, 0.0, __builtin_fma(y, 0.0, z * 0.0)) == 0.0);
+  // finite AND representable after squaring: a finite target beyond ~1e154 overflows x * x (num, sig2 or rho2 = inf), rsqrt_nr(inf)
+  // is 0 and its Newton step inf * 0 = NaN - the reference clamps d = inf to 1 and commands finite, saturated torques
+  // (kinematics.cpp:131-134), which is what the reference-shaped evaluation below returns
+  const bool finite = (__builtin_fma(num, 0.0, __builtin_fma(sig2, 0.0, rho2 * 0.0)) == 0.0);
   double d = num / (2.0 * l2 * l3);  // (a true division, as the reference's: within a few ulps of |d| = 1 every ulp of d is a different knee angle)
   if (d > 1.0) d = 1.0;
   // d < -1 (the reference point inside the inner reach limit; the reference clamps d > 1 only, kinematics.cpp:131-134) makes

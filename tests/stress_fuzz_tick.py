@@ -11,7 +11,8 @@ from oracle import c_oracle as O
 
 
 def run(batches=30, n=4096, budget_s=None, min_batches=3):
-    """Returns (worst GRF error, worst torque error / tau_max, torque entries off by > 1e-6, status mismatches, batches done)."""
+    """Returns (worst GRF error, worst torque error / tau_max, torque entries off by > 1e-6, status mismatches, batches done,
+    torque entries that are NaN on one side only)."""
     rng = np.random.default_rng(int(os.environ.get("QC_FUZZ_SEED", 999)))  # QC_FUZZ_SEED: another campaign (the default is the one pytest runs)
     worst = 0.0; worst_f = 0.0; mism = 0; t0 = time.time(); flips = 0; nan_mismatch = 0
     for bi in range(batches):
@@ -51,6 +52,10 @@ def run(batches=30, n=4096, budget_s=None, min_batches=3):
         big = d > 1e-6
         flips += int(big.sum())
         worst_f = max(worst_f, ef); worst = max(worst, float(np.nanmax(d)))
+        if one_nan.any():
+            i, j = np.argwhere(one_nan)[0]
+            print("batch %d spread %.1f: %d torque entries NaN on one side only (first: robot %d joint %d: gpu %r oracle %r, swing_pos %s)" %
+                  (bi, spread, int(one_nan.sum()), i, j, o["joint_tau"][i, j], ref["joint_tau"][i, j], b["swing_pos"][i].reshape(4, 3)[j // 3]))
         if ef > 1e-6 or big.any() or mism:
             i, j = np.unravel_index(np.argmax(d), d.shape)
             print("batch %d spread %.1f: grf err %.2e, torque err %.2e of tau_max (robot %d joint %d: gpu %.6f oracle %.6f, stance %s), %d entries > 1e-6, status mismatches %d" %
@@ -58,7 +63,7 @@ def run(batches=30, n=4096, budget_s=None, min_batches=3):
     print("%d batches x %d robots in %.0f s: worst grf err %.2e, worst torque err %.2e of tau_max, entries > 1e-6: %d of %d, status mismatches %d, "
           "entries NaN on one side only: %d" %
           (bi + 1, n, time.time() - t0, worst_f, worst, flips, (bi + 1) * n * 12, mism, nan_mismatch))
-    return worst_f, worst, flips, mism, bi + 1
+    return worst_f, worst, flips, mism, bi + 1, nan_mismatch
 
 
 if __name__ == "__main__":

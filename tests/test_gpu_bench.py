@@ -53,6 +53,29 @@ def test_bench_line_single_gpu(built):
     assert len(d["kernel_src_sha16"]) == 16
 
 
+def test_bench_complete_tick_advances_the_gait_clock(built):
+    """`--tick full` times the COMPLETE tick - the on-device gait clock advances by 1/300 s per launch, so
+    stance -> swing edges (foothold replanning + trajectory reset) happen inside the timed region at their natural rate; the line
+    reports the realised rate, prices the roofline with it, and the phases the device left behind equal the replayed clock."""
+    r = subprocess.run([sys.executable, "bench.py", "--tick", "full", "--config", "3", "--robots", "8192", "--steps", "24", "--warmup", "3",
+                        "--no-sweep", "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    g = d["gait_clock"]
+    assert d["config"]["tick"] == "full" and abs(g["dt_s"] - 1 / 300) < 1e-15 and sum(g["timed_ticks_per_set"]) == 24
+    assert g["stance_to_swing_edges"] > 0 and g["device_phase_vs_replayed_clock_max_abs"] == 0.0
+    assert abs(g["edge_legs_per_robot_tick"] - g["expected_edge_legs_per_robot_tick"]) < 0.3 * g["expected_edge_legs_per_robot_tick"]
+    per = 964 + 8 + 32 + 48 * g["edge_legs_per_robot_tick"]
+    assert abs(d["roofline"]["bytes_per_launch"] - per * 8192) < 1e-6 * per * 8192
+    assert d["solved_fraction"] == 1.0
+    # the frozen-phase protocol of rounds 3-4 stays available
+    r = subprocess.run([sys.executable, "bench.py", "--tick", "full-frozen", "--config", "3", "--robots", "8192", "--steps", "10", "--warmup", "3",
+                        "--no-sweep", "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    assert "gait_clock" not in d and d["roofline"]["bytes_per_launch"] == 964 * 8192
+
+
 def _check_two_rank_line(d, total):
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["global_batch"] == total
     assert d["config"]["robots_per_gpu"] == total // 2 and d["config"]["workload"].startswith("config5")

@@ -788,6 +788,30 @@ def test_non_finite_joint_states_in_the_widened_tick(q):
     assert np.abs(o["joint_tau"] - ref["joint_tau"])[m].max() < 2e-5
 
 
+def test_huge_finite_swing_references_saturate_like_the_reference(q):
+    """a FINITE swing reference beyond ~1e154 m overflows its own square.  The reference clamps the knee cosine
+    d = inf to 1 (kinematics.cpp:131-134) and commands finite angles - a saturated, finite torque; the device's trig-free IK
+    must hand such targets to its reference-shaped evaluation instead of returning NaN from rsqrt(inf)."""
+    from oracle import c_oracle as O
+    from quadruped_control_amd import workloads as W
+
+    P = q.cheetah_params(0.6)
+    n = 2048
+    b = W.with_swing_references(W.with_joint_angles(W.config3(n)))
+    sp = b["swing_pos"].copy()
+    for k, (col, val) in enumerate(((0, 1e160), (1, -1e200), (2, 3e155), (4, 1e300), (8, -2e180), (9, 1e154), (11, 1e153))):
+        sp[k::7, col] = val
+    b = dict(b, swing_pos=sp)
+    o = q.BalanceController.from_params(P).control_batch_host(b, want_torques=True)
+    ref = O.tick_swing_batch(P, b, threads=8)
+    assert np.array_equal(o["status"], ref["status"])
+    assert np.array_equal(np.isnan(o["joint_tau"]), np.isnan(ref["joint_tau"]))
+    swing = np.repeat(b["stance"] == 0, 3, axis=1)
+    assert np.isfinite(ref["joint_tau"][swing]).mean() > 0.9  # the reference saturates, it does not give up
+    m = ~np.isnan(ref["joint_tau"])
+    assert np.abs(o["joint_tau"] - ref["joint_tau"])[m].max() < 2e-5
+
+
 def test_non_finite_states_in_the_stateful_tick(q):
     """NaN velocities / inf positions / NaN gait phases over a sequence of planned ticks: the carried swing state,
     the statuses and the NaN pattern of the torques follow the oracle (std::clamp of the trajectory time,

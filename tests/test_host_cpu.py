@@ -12,15 +12,19 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 def test_abi_exports_match_header(built):
     hdr = open(os.path.join(ROOT, "include", "qc_balance.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    inline = set(re.findall(r"static inline \w+ (qc_[a-z_]+)\s*\(", hdr))
+    assert inline == {"qc_create"}  # ABI v6: the ABI guard travels with the constructor every C / C++ caller writes
+    hdr = re.sub(r"static inline [^{]*\{.*?\n\}", "", hdr, flags=re.S)
     declared = set(re.findall(r"\b(qc_[a-z_]+)\s*\(", hdr))
-    assert {"qc_create", "qc_destroy", "qc_control_batch", "qc_control_batch_host", "qc_control", "qc_last_error"} <= declared
+    assert {"qc_create_abi", "qc_destroy", "qc_control_batch", "qc_control_batch_host", "qc_control", "qc_last_error"} <= declared
     lib = ctypes.CDLL(os.path.join(ROOT, "quadruped_control_amd", "libqc_balance.so"))
+    assert not hasattr(lib, "qc_create")  # a binary built against ABI <= 5 fails to load instead of running unguarded
     for name in declared:
         assert hasattr(lib, name), f"libqc_balance.so lacks {name}"
     from quadruped_control_amd import _lib
 
     assert set(_lib.EXPORTS) == declared
-    assert _lib.load().qc_abi_version() == _lib.ABI_VERSION == 5
+    assert _lib.load().qc_abi_version() == _lib.ABI_VERSION == 6
     m = re.search(r"#define QC_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "qc_balance.h")).read())
     assert int(m.group(1)) == _lib.ABI_VERSION
 
@@ -34,11 +38,17 @@ def test_abi_check_refuses_a_caller_built_against_another_revision(built):
     lib = _lib.load()  # (has already passed the check with this package's own structures)
     sizes = (ctypes.sizeof(_lib.QcParams), ctypes.sizeof(_lib.QcBatchIn), ctypes.sizeof(_lib.QcBatchOut))
     assert lib.qc_check_abi(_lib.ABI_VERSION, *sizes) == _lib.QC_OK
-    assert lib.qc_check_abi(_lib.ABI_VERSION - 1, *sizes) == _lib.QC_ERR_ABI  # an ABI v4 caller
-    assert "ABI v4" in _lib.last_error() and "ABI v5" in _lib.last_error()
+    assert lib.qc_check_abi(_lib.ABI_VERSION - 1, *sizes) == _lib.QC_ERR_ABI  # an ABI v5 caller
+    assert "ABI v5" in _lib.last_error() and "ABI v6" in _lib.last_error()
     assert lib.qc_check_abi(_lib.ABI_VERSION, sizes[0], sizes[1] - 8, sizes[2]) == _lib.QC_ERR_ABI  # ABI v2's qc_batch_in (no gait_dt)
     assert lib.qc_check_abi(_lib.ABI_VERSION, sizes[0], sizes[1], sizes[2] - 8) == _lib.QC_ERR_ABI  # ABI v1's qc_batch_out (no joint_tau)
-    # the adapter and the loader do call it
+    # the guard is not advisory any more - the constructor itself refuses (no device needed to get that far)
+    h = ctypes.c_void_p()
+    p = _lib.QcParams()
+    assert lib.qc_create_abi(ctypes.byref(p), 0, ctypes.byref(h), _lib.ABI_VERSION - 1, *sizes) == _lib.QC_ERR_ABI and not h.value
+    assert lib.qc_create_abi(ctypes.byref(p), 0, ctypes.byref(h), _lib.ABI_VERSION, sizes[0], sizes[1] - 8, sizes[2]) == _lib.QC_ERR_ABI and not h.value
+    assert "qc_batch_in" in _lib.last_error()
+    # the adapter and the loader also call the device-free check
     assert "QC_CHECK_ABI()" in open(os.path.join(ROOT, "include", "qc_balance_controller.hpp")).read()
     assert "qc_check_abi(ABI_VERSION" in open(os.path.join(ROOT, "quadruped_control_amd", "_lib.py")).read()
 
@@ -216,18 +226,62 @@ def test_bench_tick_workloads_and_byte_counts():
     assert bench.bytes_per_robot(False) == 488 == 48 * 8 + 4 + 12 * 8 + 4
     assert bench.bytes_per_robot(True) == 496
     assert bench.bytes_per_robot(False, True) == 584 == 488 + 96                      # + joint_tau
-    assert bench.bytes_per_robot(False, "full") == 964 == (384 + 32 + 96 + 224) + (96 + 4 + 96 + 32)
+    assert bench.bytes_per_robot(False, "full-frozen") == 964 == (384 + 32 + 96 + 224) + (96 + 4 + 96 + 32)
+    # the clocked complete tick: + gait_dt read + advanced phases written + 48 B per stance -> swing edge
+    assert bench.bytes_per_robot(False, "full") == 964 + 8 + 32 == 1004
+    assert abs(bench.bytes_per_robot(False, "full", edge_legs=4.0 / 294.0) - (1004 + 48 * 4.0 / 294.0)) < 1e-12
     assert bench.rotation_sets(4096, False) == 269 and bench.rotation_sets(65536, False) == 17
-    assert bench.rotation_sets(65536, False, "full") == (512 << 20) // (964 * 65536) + 1 == 9
-    assert bench.rotation_sets(262144, False, "full") == 3 and bench.rotation_sets(2097152, False) == 1
+    assert bench.rotation_sets(65536, False, "full-frozen") == (512 << 20) // (964 * 65536) + 1 == 9 == bench.rotation_sets(65536, False, "full")
+    assert bench.rotation_sets(262144, False, "full") == 3 == bench.rotation_sets(262144, False, "full-frozen") and bench.rotation_sets(2097152, False) == 1
+    assert isinstance(bench.rotation_sets(262144, False, "full"), int)
     fused = bench.make_tick_batch(2, 64, 0, True)
     assert "feet" not in fused and fused["joint_q"].shape == (64, 12) and fused["stance"].shape == (64, 4)
     full = bench.make_tick_batch(3, 64, 128, "full", j=2)
     assert {"joint_q", "joint_qdot", "gait_phase"} <= set(full) and not {"stance", "swing_pos", "swing_vel", "feet"} & set(full)
     assert full["gait_phase"].shape == (64, 4) and (full["gait_phase"] >= 0).all() and (full["gait_phase"] < 1).all()
+    assert full["gait_dt"].shape == (64,) and (full["gait_dt"] == 1.0 / 300.0).all()  # mit_cheetah_config.yaml:3
+    frozen = bench.make_tick_batch(3, 64, 128, "full-frozen", j=2)
+    assert "gait_dt" not in frozen and set(frozen) | {"gait_dt"} == set(full)
+    np.testing.assert_array_equal(frozen["gait_phase"], full["gait_phase"])
     # rotation sets hold different robots of the same distribution; a shard is reproducible from its start index
     other = bench.make_tick_batch(3, 64, 128, "full", j=0)
     assert not np.array_equal(full["joint_q"], other["joint_q"])
     np.testing.assert_array_equal(bench.make_tick_batch(3, 32, 160, "full", j=2)["joint_q"], full["joint_q"][32:])
     assert "EPYC" in bench.cpu_model() or len(bench.cpu_model()) > 3
     assert bench.oracle_build_flags().startswith(("gcc", "cc")) and "-ffp-contract=off" in bench.oracle_build_flags()
+
+
+def test_bench_counts_the_gait_edges_its_timed_region_contains(built):
+    """the complete-tick entries advance the on-device gait clock inside the timed region and report the
+    realised stance -> swing edge rate (each edge = one FootPlanner::singleFoot + trajectory reset on the device).  bench.py
+    counts the edges by replaying the clock on a snapshot; here that replay is checked against the oracle's
+    GaitScheduler::update + the package's contact rule, tick by tick, on sets that run different numbers of ticks."""
+    import torch
+
+    import bench
+    from oracle import c_oracle as O
+    from quadruped_control_amd import leg_state_from_phase, stance_phase
+
+    n, per_set = 500, [7, 12, 0]
+    rng = np.random.default_rng(3)
+    ph0 = np.ascontiguousarray(np.fmod(np.array([0.0, 0.5, 0.5, 0.0])[None] + rng.uniform(0, 1, (3 * n, 1)), 1.0))
+    kin = O.default_kinematics()
+    assert (kin.t_swing, kin.t_stance) == (bench.GAIT_T_SWING, bench.GAIT_T_STANCE)
+    duty = stance_phase(kin.t_swing, kin.t_stance)
+    ref = ph0.copy()
+    edges = robots_edge = 0
+    for j, c in enumerate(per_set):
+        ph = np.ascontiguousarray(ref[j * n:(j + 1) * n])
+        st = leg_state_from_phase(ph, duty).astype(bool)
+        for _ in range(c):
+            O.gait_update(ph, np.full(n, bench.GAIT_DT), kin=kin)
+            st_new = leg_state_from_phase(ph, duty).astype(bool)
+            e = st & ~st_new
+            edges += int(e.sum()); robots_edge += int(e.any(axis=1).sum())
+            st = st_new
+        ref[j * n:(j + 1) * n] = ph
+    got = bench.count_gait_edges(torch.from_numpy(ph0), per_set, n, torch.from_numpy(ref))
+    assert got[0] == edges > 0 and got[1] == 4 * n * sum(per_set) and got[2] == robots_edge and got[3] == n * sum(per_set)
+    assert got[4] == 0.0  # the replayed clock is bit-equal to the oracle's
+    # natural rate: one edge per leg per gait period
+    assert abs(edges / (n * sum(per_set)) - 4 * bench.GAIT_DT / 0.98) < 0.004

@@ -405,6 +405,48 @@ def test_pinv3_converges_on_an_exactly_rank_deficient_jacobian():
         np.testing.assert_allclose(Ap, ref, atol=1e-10 * max(1.0, np.abs(ref).max()))
 
 
+def test_pinv_band_takes_its_rank_from_the_device_rule():
+    """inside the band where this build answers legJacobianInverse with the pseudo-inverse (|det| below
+    max(epsilon, 64 epsilon (sum |l|)^3)) the device's pinv3_apply never takes a third pivot and drops a second one below 1e-9
+    of the first, while Armadillo's tolerance (3 sigma_max epsilon) would keep sigma_3 down to ~1e-16 sigma_1: for |det|
+    between ~1e-17 and the band's upper end the two would be a rank-2 and a rank-3 pseudo-inverse.  The granularity of the knee
+    cosine makes that window all but unreachable (test_inv_pinv_switch_has_numbers), but the checker must not lean on that:
+    oracle_pinv3_band takes the RANK from the device's rule and only the values from the SVD.  Planted matrices:"""
+    eps = np.finfo(float).eps
+    rng = np.random.default_rng(11)
+    lo = max(eps, 64 * eps * 0.518 ** 3)
+
+    def with_sv(s):
+        U, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        V, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        return U @ np.diag(s) @ V.T
+
+    for s3 in (6e-14, 3e-14, 1e-15, 1e-17, 0.0):  # |det| = 0.03 s3: just below the band's upper end ... exact rank loss
+        J = with_sv([0.3, 0.1, s3])
+        assert abs(np.linalg.det(J)) < lo
+        Jb, rank = O.pinv3_band(J)
+        assert rank == 2
+        np.testing.assert_allclose(Jb, np.linalg.pinv(J, rcond=0.1), atol=1e-10)  # numpy told to keep two singular values
+        assert np.abs(Jb).max() < 20.0
+        Ja, ok = O.pinv3(J)  # Armadillo's tolerance alone: a 1 / s3-sized gain as long as s3 > 3 eps sigma_1
+        assert ok and ((np.abs(Ja).max() > 0.1 / s3) if s3 >= 1e-15 else np.allclose(Ja, Jb, atol=1e-9))
+    # rank 1 (the lateral clamp on top of a stretched knee): second pivot below 1e-9 of the first
+    for s2 in (1e-11, 1e-14, 0.0):
+        J = with_sv([0.4, s2, 0.0])
+        Jb, rank = O.pinv3_band(J)
+        assert rank == 1
+        np.testing.assert_allclose(Jb, np.linalg.pinv(J, rcond=0.1), atol=1e-10)
+    # on the exactly rank-deficient Jacobians IK produces the two rules agree: nothing changes for reachable inputs
+    for trial in range(3000):
+        A = rng.normal(size=(3, 3)) * 10.0 ** rng.uniform(-2, 0)
+        if trial % 2: A[:, 2] = A[:, 1] * rng.normal()
+        else: A = np.outer(A[:, 0], A[0])
+        Jb, rank = O.pinv3_band(A)
+        Ja, ok = O.pinv3(A)
+        assert ok and rank == (2 if trial % 2 else 1)
+        np.testing.assert_allclose(Jb, Ja, atol=1e-9 * max(1.0, np.abs(Ja).max()))
+
+
 def test_reference_inside_the_inner_reach_limit_gives_nan_torques():
     """legInverseKinematics clamps the knee cosine from above only (d > 1 -> 1, kinematics.cpp:131-134): a swing reference closer
     to the hip than | |l2| - |l3| | has d < -1, q3 = atan2(-sqrt(1 - d^2), d) = NaN, q2 = NaN, the Jacobian at q_ref is NaN, and
