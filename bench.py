@@ -811,6 +811,23 @@ def main():
                                           "this batch (strong scaling), so a 1/2/4/8 curve starts HERE, not at this line's `value`"}
             del r
             torch.cuda.empty_cache()
+            # the dense 12x12 form (a general SPD W is part of the reference's constructor contract, balance_controller.hpp:76-77, 85-88),
+            # forced on the reference's diagonal W so that the workloads are the headline's: four lanes per robot with racing
+            # strategies at config 2's size, one lane per robot with the Hessian staged in LDS at config 3's
+            dense = q.BalanceController.from_params(P, device=device).set_tuning(force_dense=1, **tune)
+            for c in (2, 3):
+                r = run_config(dense, q, c, CONFIG_N[c], 0, k, 10, None, device, warm_ms=args.device_warm_ms)
+                info_d = dense.query_launch(CONFIG_N[c])
+                e = {"robots": CONFIG_N[c], "solved_fraction": r["solved_all_sets"] / (r["sets"] * CONFIG_N[c]), "sets": r["sets"], "steps": k,
+                     "kernel": dense.kernel_name, "lanes_per_robot": info_d["lanes_per_robot"], "kernel_mode": info_d["mode"],
+                     "resident_workgroups": info_d["resident_workgroups"], "lds_bytes": info_d["lds_bytes"],
+                     "cold_cache": rates(r, "cold", CONFIG_N[c], k, BYTES_PER_ROBOT_COLD), "warm_cache": rates(r, "warm_cache", CONFIG_N[c], k, BYTES_PER_ROBOT_COLD),
+                     "what": "qc_set_tuning force_dense = 1: the formulation a non-diagonal W selects, on this config's robots"}
+                attach_pmc(e, c, CONFIG_N[c], sha, dense.kernel_name, kernel_us=e["cold_cache"]["avg_kernel_us"])
+                other[f"dense_config{c}"] = e
+                del r
+                torch.cuda.empty_cache()
+            del dense
             # the ticks built around the QP, under the same cold-cache protocol as the hot path
             for key, c, nn, fz, what in (
                     ("config2_fused_tick", 2, CONFIG_N[2], True, "joint_q -> forward kinematics -> control() -> clamp(J^T f) -> joint_tau in one launch"),

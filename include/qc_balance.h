@@ -230,7 +230,7 @@ int qc_check_abi(int abi_version, size_t sizeof_params, size_t sizeof_batch_in, 
  * strategies per robot there, `strategies`; 3 paired waves - two one-lane waves per workgroup, the last to arrive
  * finishes both waves' stragglers: 6x6 forms from 524 288 robots on), form (0 uniform 6x6, 1 general 6x6, 2 dense 12x12),
  * robots per wave, grid size, and the workgroups of that kernel the device holds at once (the occupancy query the
- * heuristics use). */
+ * heuristics use).  (Mode 0 is reported by development builds only: the default library runs every form as one-fill workgroups.) */
 typedef struct qc_launch_info {
   int32_t lanes_per_robot;
   int32_t mode;
@@ -245,10 +245,9 @@ int qc_query_launch(qc_handle* h, size_t n, int kin, int warm, qc_launch_info* o
 
 /* ABI v4.  Development / test interface: explicit overrides of the launch heuristics and solver constants (the
  * library reads NO environment variables).  Keys: "group" (lanes per robot: 0 = heuristic, 1, 2, 4), "one_fill"
- * (-1 heuristic, 0 persistent waves, 1 one-fill workgroups; the persistent kernels of the 6x6 forms exist only in
- * development builds, -DQC_PERSISTENT_6X6=1: elsewhere 0 applies to the one-lane dense form and a launch of a 6x6 form
- * with it fails with QC_ERR_INVALID), "chunk" (robots per wave, 0 = heuristic; beyond one fill only where persistent
- * kernels exist - QC_ERR_INVALID at launch otherwise),
+ * (-1 heuristic, 0 persistent waves, 1 one-fill workgroups; the persistent kernels exist only in development builds,
+ * -DQC_PERSISTENT_6X6=1: elsewhere a launch with 0 fails with QC_ERR_INVALID), "chunk" (robots per wave, 0 = heuristic;
+ * beyond one fill only where persistent kernels exist - QC_ERR_INVALID at launch otherwise),
  * "wave_slots" (resident workgroups assumed, 0 = occupancy query), "refill_t", "rounds_cold", "rounds_warm",
  * "race" (-1 heuristic; 0 or 1: one strategy per robot; 2, 4: at most that many racing in the 4-lane one-fill kernels),
  * "pair" (-1 heuristic, 0 never, 1 whenever one lane per robot on a 6x6 form: the paired-waves kernel, mode 3), "pair_th"

@@ -960,8 +960,15 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
   constexpr int G = Eqp::G;
   extern __shared__ __attribute__((aligned(16))) double qc_lds[];  // [stock planes][64] (+ the dense form's 78 Hessian planes)
   constexpr int SP = stock_slots(G, MODE) + 1;  // plane stride of this mode's stock
+  // One-lane dense form as one-fill workgroups (round 5): the 78 Hessian planes (39 936 B) ARE the workgroup's LDS - four
+  // workgroups per CU, one per SIMD.  With the stock in front of them (58.3 KB) a CU held two, i.e. every other SIMD idled
+  // behind the 512-register kernel.  The input stock is not used on this path (one lane assembles and solves its robot),
+  // Rwb is read again for the output transform instead of parked, and the output stock aliases the first Hessian planes
+  // once every robot of the wave is finished.
+  constexpr bool HESS_ONLY = Eqp::kHessianInLds && MODE != 0;
+  static_assert(!HESS_ONLY || (OUT_PLANES * SP + TASK_DOUBLES <= 78 * 64), "the output stock fits the Hessian planes it aliases");
   double* const sin = qc_lds;
-  double* const sout = qc_lds + IN_PLANES * SP;
+  double* const sout = HESS_ONLY ? qc_lds : qc_lds + IN_PLANES * SP;
   long cursor = (long)blockIdx.x * chunk;  // wave-uniform: next robot of this wave's chunk to assemble
   const long end = cursor + chunk < n ? cursor + chunk : n;
   const int lane = threadIdx.x;
@@ -973,7 +980,7 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
   Lane<Eqp, KIN, (RACE > 1)> L;
   L.idx = -1;
   L.foot0 = member * (4 / G);
-  Eqp eqp(qc_lds + stock_doubles(stock_slots(G, MODE)) + lane);
+  Eqp eqp(qc_lds + (HESS_ONLY ? 0 : stock_doubles(stock_slots(G, MODE))) + lane);
   bool busy = false;  // group holds an unfinished robot
   QC_CLK_BEGIN();
   if constexpr (MODE != 0) {
@@ -988,7 +995,8 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
     // assembly into the solver's registers - no input stock, no barrier - and its Rwb is parked in the first nine planes of
     // the (otherwise idle) input-stock area for the output transform; the planes behind them serve as the re-pack area of the tail.
     constexpr bool DIRECT = G == 1;
-    constexpr int R_PLANES = DIRECT ? 9 : 0;
+    constexpr bool RPARK = DIRECT && !HESS_ONLY;  // Rwb parked in LDS for the output transform
+    constexpr int R_PLANES = RPARK ? 9 : 0;
     static_assert(!DIRECT || (R_PLANES * SP + 16 * REPACK_RS <= IN_PLANES * SP), "Rwb planes + re-pack records fit the input-stock area");
     if constexpr (DIRECT) {
       const long left = end - cursor;
@@ -1012,8 +1020,10 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
         CParams& P = *QC_PARAMS_HERE(Pg);
         Wrench<4> W;
         const uint32_t st = assemble_from_state<KIN, 4, false>(P, ia, robot, 0, S, fp, sw, X, W);
+        if constexpr (RPARK) {
 #pragma unroll
-        for (int k = 0; k < 9; k++) sin[k * SP + lane] = S.R[k];
+          for (int k = 0; k < 9; k++) sin[k * SP + lane] = S.R[k];
+        }
         L.load_direct(W, st, wv, robot, 0);
       }
     } else {
@@ -1157,11 +1167,12 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
           busy = !L.template iterate<LaneT::STEADY>(*QC_PARAMS_HERE(Pg), eqp);
         }
       }
+      if constexpr (HESS_ONLY) __syncthreads();  // every lane is past its last read of the Hessian planes the output stock aliases
       if (mine) L.template push_result<SP>(sout, grp);
     }
     QC_CLK(7, 8);
     __syncthreads();
-    flush_out<Eqp::G, KIN, STR, SP, DIRECT>(Pg, in, out, sout, stock_n, lane, DIRECT ? sin : nullptr);
+    flush_out<Eqp::G, KIN, STR, SP, RPARK>(Pg, in, out, sout, stock_n, lane, RPARK ? sin : nullptr);
     QC_CLK_END(8);
     return;
   }
@@ -1613,15 +1624,15 @@ static int upload_params(qc_handle* h) {
 // there, cold and warm).  Every width finishes its last <= 16 running robots on the 4-lane body.  Batches up to
 // `rounds` times the resident one-fill workgroups run as one-fill workgroups - the hardware scheduler does the
 // refill; with the one-lane kernel that wins at every size measured (2 M robots cold: 633 us against 676 us as
-// persistent waves), so `rounds` is unbounded for the 6x6 forms and the persistent kernels (waves walking
-// contiguous chunks with lane refill) serve the one-lane dense form and qc_set_tuning("one_fill", 0).
+// persistent waves), so `rounds` is unbounded and the persistent kernels (waves walking contiguous chunks with lane
+// refill) serve qc_set_tuning("one_fill", 0) in development builds only.
 enum { QC_FORM_UNIFORM = 0, QC_FORM_GENERAL = 1, QC_FORM_DENSE = 2 };
-// The persistent-wave (MODE 0) kernels of the 6x6 forms - round 1's large-batch kernels, which the planner has not picked
-// for any batch since the one-lane one-fill kernel exists - are compiled only into development builds
-// (-DQC_PERSISTENT_6X6=1: tools/build_dev.sh, the A/B scans, QC_TEST_PERSISTENT_6X6=1 in tests/test_gpu_matrix.py): twelve
-// instantiations with up to 672 B of scratch per lane that a default handle can never launch.  Without them the 6x6
-// forms always run as one-fill workgroups and qc_set_tuning("one_fill", 0) / chunks beyond one fill apply to the dense
-// form only (whose one-lane kernel still walks chunks beyond one round of workgroups).
+// The persistent-wave (MODE 0) kernels - round 1's large-batch kernels, which the planner has not picked for any batch of a
+// 6x6 form since the one-lane one-fill kernel exists (round 2) nor for the one-lane dense form since its LDS diet (round 5:
+// one-fill workgroups resident once per SIMD win at every size) - are compiled only into development builds
+// (-DQC_PERSISTENT_6X6=1: the A/B scans, QC_TEST_PERSISTENT_6X6=1 in tests/test_gpu_matrix.py): fourteen instantiations with
+// up to 672 B of scratch per lane that a default handle can never launch.  Without them every form runs as one-fill
+// workgroups and qc_set_tuning("one_fill", 0) / a chunk beyond one fill is an error at launch.
 #ifndef QC_PERSISTENT_6X6
 #define QC_PERSISTENT_6X6 0
 #endif
@@ -1647,13 +1658,19 @@ static qc_kernel_fn kernel_for(int form, int G, int mode, bool kin, int minw = 2
   }
 #endif
   (void)minw;
-  if (form == QC_FORM_DENSE && G == 4) return race == 4 ? kernel_of<EqpDense4, 1, 1, 4>(kin) : (race == 2 ? kernel_of<EqpDense4, 1, 1, 2>(kin) : kernel_of<EqpDense4, 1, 1>(kin));
-  if (form == QC_FORM_DENSE) return mode ? kernel_of<EqpDense, 1, 1>(kin) : kernel_of<EqpDense, 1, 0>(kin);
+#ifdef QC_DEV_ONLY_DENSE1  // development: compile the one-lane dense kernels alone (seconds instead of a minute; tools/kernel_resources.py)
+  (void)form; (void)G; (void)race;
+  return kernel_of<EqpDense, 1, 1>(kin);
+#else
 #if QC_PERSISTENT_6X6
 #define QC_MODE0(EQP) kernel_of<EQP, 2, 0>(kin)
+#define QC_MODE0_DENSE kernel_of<EqpDense, 1, 0>(kin)
 #else
-#define QC_MODE0(EQP) nullptr /* the planner never asks: plan_launch keeps the 6x6 forms on one-fill workgroups */
+#define QC_MODE0(EQP) nullptr /* the planner never asks: plan_launch keeps every form on one-fill workgroups */
+#define QC_MODE0_DENSE nullptr
 #endif
+  if (form == QC_FORM_DENSE && G == 4) return race == 4 ? kernel_of<EqpDense4, 1, 1, 4>(kin) : (race == 2 ? kernel_of<EqpDense4, 1, 1, 2>(kin) : kernel_of<EqpDense4, 1, 1>(kin));
+  if (form == QC_FORM_DENSE) return mode ? kernel_of<EqpDense, 1, 1>(kin) : QC_MODE0_DENSE;
   if (form == QC_FORM_GENERAL) {
     if (G == 4 && mode && STR && race == 4) return kernel_of<EqpDiagW<false, 4, STR>, 2, 1, (STR ? 4 : 1)>(kin);
     if (G == 4 && mode && STR && race == 2) return kernel_of<EqpDiagW<false, 4, STR>, 2, 1, (STR ? 2 : 1)>(kin);
@@ -1667,16 +1684,24 @@ static qc_kernel_fn kernel_for(int form, int G, int mode, bool kin, int minw = 2
   if (G == 2) return mode ? kernel_of<EqpDiagW<true, 2>, 2, 1>(kin) : QC_MODE0(QC_COMMA(EqpDiagW<true, 2>));
   return mode ? kernel_of<EqpDiagW<true, 1>, 2, 1>(kin) : QC_MODE0(QC_COMMA(EqpDiagW<true, 1>));
 #undef QC_MODE0
+#undef QC_MODE0_DENSE
+#endif  // QC_DEV_ONLY_DENSE1
 }
 typedef void (*qc_pair_kernel_fn)(const qc::DevParams*, long, qc::BatchIn, const uint32_t*, qc::BatchOut, int, int, int, unsigned);
 static qc_pair_kernel_fn pair_kernel_for(int form) {
   using namespace qc;
+#ifdef QC_DEV_ONLY_DENSE1
+  (void)form;
+  return nullptr;
+#else
   return form == QC_FORM_UNIFORM ? (qc_pair_kernel_fn)balance_pair_kernel<EqpDiagW<true, 1>, false> : (qc_pair_kernel_fn)balance_pair_kernel<EqpDiagW<false, 1>, false>;
+#endif
 }
 static size_t lds_for(int form, int G, int mode) {
   if (mode == 3) return 0;  // (static LDS: Rwb rows, record list, two counters)
 
   const size_t stock = (size_t)qc::stock_doubles(qc::stock_slots(G, mode)) * sizeof(double);
+  if (form == QC_FORM_DENSE && G != 4 && mode != 0) return (size_t)78 * 64 * sizeof(double);  // the Hessian planes alone (balance_kernel: HESS_ONLY)
   if (form == QC_FORM_DENSE) return stock + (G == 4 ? (size_t)qc::EqpDense4::X_DOUBLES : (size_t)78 * 64) * sizeof(double);
   return stock;
 }
@@ -1719,14 +1744,14 @@ static int plan_launch(qc_handle* h, long n, bool kin, bool warm, qc_launch_plan
     // latency regime; one lane per robot with the LDS-staged Hessian above that
     G = n <= cap4 ? 4 : 1;
     if (h->group_override) G = h->group_override == 4 ? 4 : 1;
-    if (G == 4 && (h->one_fill_override == 0 || h->chunk_override > 16)) G = 1;
+    if (QC_PERSISTENT_6X6 && G == 4 && (h->one_fill_override == 0 || h->chunk_override > 16)) G = 1;
   }
   lp->pfn = nullptr;
   lp->p_th = lp->p_refill = 0;
   // A request this build cannot honour is an error, not a silent fall-back to one-fill workgroups: the persistent (mode 0)
   // kernels of the 6x6 forms exist only in -DQC_PERSISTENT_6X6=1 builds.
-  if (!QC_PERSISTENT_6X6 && form != QC_FORM_DENSE && (h->one_fill_override == 0 || h->chunk_override > 64 / G))
-    return fail(QC_ERR_INVALID, "qc_set_tuning: one_fill = 0 / a chunk beyond one fill asks for a persistent-wave kernel of a 6x6 form, which this "
+  if (!QC_PERSISTENT_6X6 && (h->one_fill_override == 0 || h->chunk_override > 64 / G))
+    return fail(QC_ERR_INVALID, "qc_set_tuning: one_fill = 0 / a chunk beyond one fill asks for a persistent-wave kernel, which this "
                                 "build does not contain (compile with -DQC_PERSISTENT_6X6=1)");
   // MODE 3 (paired waves): 6x6 forms, one lane per robot, batches of at least four rounds of one-fill workgroups (524 288
   // robots): measured -5 % there and nothing below (profiles/r03_paired_waves.log) - with few rounds the consumer of two
@@ -1760,8 +1785,10 @@ static int plan_launch(qc_handle* h, long n, bool kin, bool warm, qc_launch_plan
   long resident = 0;
   if (can_one_fill) {
     resident = resident_workgroups(h, (const void*)kernel_for(form, G, 1, kin, h->min_waves), lds_for(form, G, 1));
-    // (the one-lane dense kernel keeps round 1's thresholds: persistent waves beyond one round of cold workgroups)
-    const double rounds = form == QC_FORM_DENSE ? (warm ? 6.0 : 1.0) : (warm ? h->rounds_warm : h->rounds_cold);
+    // (round 5: the one-lane dense kernel too - with the Hessian planes as its only LDS it is resident once per SIMD and, as
+    // one-fill workgroups, beats its persistent form at every size: 65 536 robots 138 vs 172 us, 262 144 317 vs 415,
+    // profiles/r05_dense_sizes.log)
+    const double rounds = warm ? h->rounds_warm : h->rounds_cold;
     one_fill = (double)n <= rounds * (double)(resident * rpw);
     // The joint_q / joint_tau variants carry the kinematics through the persistent loop and spill 400-700 B per
     // lane there; as one-fill workgroups they stay at <= 68 B and win at every size.
@@ -1769,7 +1796,7 @@ static int plan_launch(qc_handle* h, long n, bool kin, bool warm, qc_launch_plan
     if (h->one_fill_override >= 0) one_fill = h->one_fill_override != 0;
     if (h->chunk_override > 0) one_fill = h->chunk_override <= rpw;
     if (form == QC_FORM_DENSE && G == 4) one_fill = true;
-    if (!QC_PERSISTENT_6X6 && form != QC_FORM_DENSE) one_fill = true;  // (the persistent 6x6 kernels are not in this build)
+    if (!QC_PERSISTENT_6X6) one_fill = true;  // (the persistent kernels are not in this build)
   }
   int mode = 0, race = 1;
   long chunk;

@@ -89,6 +89,13 @@ typedef const __attribute__((address_space(4))) DevParams CParams;
     asm volatile("" : "+s"(p_));          \
     (CParams*)(unsigned long long)p_;      \
   })
+// ... and from a reference to the constants (inside the EQP structs, which are handed a CParams&)
+#define QC_PARAMS_AGAIN(ref)                             \
+  ({                                                     \
+    unsigned long long p_ = (unsigned long long)&(ref);  \
+    asm volatile("" : "+s"(p_));                         \
+    (CParams*)p_;                                        \
+  })
 
 // The handful of constants one working-set recalculation of the UNIFORM form reads, as a register-resident
 // copy (VGPRs, pinned): used by the one-wave-per-SIMD launch of small batches, where a scalar load + wait at the
@@ -1158,6 +1165,7 @@ QC_DEV bool eqp_diagw(const PT& P, const FootW (&lane_w)[4 / G], const Wrench<4 
 template <bool UNIFORM, int GROUP, bool STRIDED = false>
 struct EqpDiagW {
   static constexpr int G = GROUP;
+  static constexpr bool kHessianInLds = false;
   static constexpr bool kStrided = STRIDED;  // lane layout of the group, see group_sum
   static constexpr bool kUniform = UNIFORM;
   static constexpr bool kRepackTail = GROUP <= 2;  // one-fill waves finish their stragglers 4 lanes per robot
@@ -1193,6 +1201,7 @@ struct EqpDiagW {
 
 struct EqpDense {
   static constexpr int G = 1;
+  static constexpr bool kHessianInLds = true;  // 78 planes x 64 lanes behind (one-fill workgroups: instead of) the stock
   static constexpr bool kStrided = false;
   static constexpr bool kRepackTail = false;
   static constexpr bool kNegB = false;
@@ -1204,17 +1213,21 @@ struct EqpDense {
   QC_DEV explicit EqpDense(double* lds_lane) : Qs(lds_lane) {}
 
   // assemble Q (into LDS) and c for the robot this lane just fetched
-  QC_DEV void setup(CParams& P, const Wrench<4>& Wr, int) {
+  QC_DEV void setup(CParams& P0, const Wrench<4>& Wr, int) {
     double Sb[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) {
       double t = 0.0;
 #pragma unroll
-      for (int m = 0; m < 6; m++) t = __builtin_fma(P.S[6 * k + m], Wr.b[m], t);
+      for (int m = 0; m < 6; m++) t = __builtin_fma(P0.S[6 * k + m], Wr.b[m], t);
       Sb[k] = t;
     }
 #pragma unroll
     for (int j = 0; j < 4; j++) {
+      // the constants of this block column (S: 36 doubles, three columns of W) are fetched HERE: with one pointer for the whole
+      // assembly the compiler issues all 180 scalar loads up front, overflows the SGPR file and parks 16-dword tuples in VGPR lanes
+      // (120-270 SGPR spills and their stack slots in the kernels that also carry the kinematic constants)
+      CParams& P = *QC_PARAMS_AGAIN(P0);
       const double rx = Wr.r[j][0], ry = Wr.r[j][1], rz = Wr.r[j][2];
       // SA_j = S [I; [r_j]x]   (6x3)
       double SA[6][3];
@@ -1276,11 +1289,13 @@ struct EqpDense {
         for (int a = 0; a < 3; a++)
 #pragma unroll
           for (int b = 0; b < 3; b++) Qb[a][b] = q(3 * i + a, 3 * j + b);
-        // gp_i += Q_ij p_j ; gp_j += Q_ij^T p_i (i != j)
+        // gp_i += Q_ij p_j ; gp_j += Q_ij^T p_i (i != j).  tz[a] = row a of Q_ij times (mu sx, mu sy, 1)_j: the z column of T_j
+        // before its mask, shared with X below
+        double tz[3];
 #pragma unroll
         for (int a = 0; a < 3; a++) {
-          const double t = Qb[a][0] * mx[j] + Qb[a][1] * my[j] + Qb[a][2];
-          gp[3 * i + a] = __builtin_fma(fzfix[j], t, gp[3 * i + a]);
+          tz[a] = __builtin_fma(Qb[a][0], mx[j], __builtin_fma(Qb[a][1], my[j], Qb[a][2]));
+          gp[3 * i + a] = __builtin_fma(fzfix[j], tz[a], gp[3 * i + a]);
         }
         if (i != j) {
 #pragma unroll
@@ -1295,13 +1310,13 @@ struct EqpDense {
         for (int a = 0; a < 3; a++) {
           X[a][0] = Qb[a][0] * ax[j];
           X[a][1] = Qb[a][1] * ay[j];
-          X[a][2] = Qb[a][0] * cx[j] + Qb[a][1] * cy[j] + Qb[a][2] * az[j];
+          X[a][2] = tz[a] * az[j];
         }
 #pragma unroll
         for (int b = 0; b < 3; b++) {
           const double h0 = ax[i] * X[0][b];
           const double h1 = ay[i] * X[1][b];
-          const double h2 = cx[i] * X[0][b] + cy[i] * X[1][b] + az[i] * X[2][b];
+          const double h2 = az[i] * __builtin_fma(mx[i], X[0][b], __builtin_fma(my[i], X[1][b], X[2][b]));
           const double h[3] = {h0, h1, h2};
 #pragma unroll
           for (int a = 0; a < 3; a++) {
@@ -1323,15 +1338,25 @@ struct EqpDense {
       y[3 * i + 2] = -(cx[i] * gp[3 * i] + cy[i] * gp[3 * i + 1] + az[i] * gp[3 * i + 2]);
     }
     const bool ok = ldlt_solve<12>(L, y);  // H = L D L^T, y <- H^-1 rhs
-    // f = T y + p
+    // f = T y + p, with the face coefficients derived from the cube states a second time (a dozen selects) instead of 20 doubles
+    // carried across the factorisation, whose 78-entry factor already fills two thirds of the register file (the laundered
+    // copies keep the compiler from merging the two derivations)
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      const double fz = __builtin_fma(az[i], y[3 * i + 2], fzfix[i]);
+      int sx = C.sx[i], sy = C.sy[i], sz = C.sz[i];
+      asm volatile("" : "+v"(sx), "+v"(sy), "+v"(sz));
+      const bool st = (stance >> i) & 1u;
+      const double ax2 = (st && sx == 0) ? 1.0 : 0.0, ay2 = (st && sy == 0) ? 1.0 : 0.0, az2 = (st && sz == 0) ? 1.0 : 0.0;
+      const double fzf = st ? (sz > 0 ? P.fzmax : (sz < 0 ? P.fzmin : 0.0)) : 0.0;
+      const double fz = __builtin_fma(az2, y[3 * i + 2], fzf);
       f[3 * i + 2] = fz;
-      f[3 * i + 0] = __builtin_fma(ax[i], y[3 * i], mx[i] * fz);
-      f[3 * i + 1] = __builtin_fma(ay[i], y[3 * i + 1], my[i] * fz);
+      f[3 * i + 0] = __builtin_fma(ax2, y[3 * i], (P.mu * (double)sx) * fz);
+      f[3 * i + 1] = __builtin_fma(ay2, y[3 * i + 1], (P.mu * (double)sy) * fz);
     }
-    // g = Q f + c
+    // g = Q f + c: Q is read from its LDS planes a second time.  Left alone the compiler keeps the 78 values of the first pass
+    // alive across the factorisation - in AGPRs, next to L's 78 in VGPRs: 600 v_accvgpr moves and 400-800 B of scratch per lane in
+    // a 2 900-instruction recalculation (rounds 1-4) - to save 39 ds_read2 instructions.
+    asm volatile("" ::: "memory");
 #pragma unroll
     for (int k = 0; k < 12; k++) g[k] = c[k];
 #pragma unroll
@@ -1362,6 +1387,7 @@ struct EqpDense {
 // wave-level fence that keeps the compiler from moving LDS reads across the writes of other lanes.
 struct EqpDense4 {
   static constexpr int G = 4;
+  static constexpr bool kHessianInLds = false;
   static constexpr bool kStrided = true;
   static constexpr bool kUniform = false;
   static constexpr bool kRepackTail = false;

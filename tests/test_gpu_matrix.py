@@ -20,8 +20,9 @@ FORM_ID = {"uniform": 0, "general": 1, "dense": 2}
 # (form, lanes per robot, mode) -> (tuning, robots): every branch of kernel_for()
 import os
 
-# The persistent-wave (mode 0) kernels of the 6x6 forms exist in development builds only (-DQC_PERSISTENT_6X6=1, which no
-# default handle can launch since round 2): QC_TEST_PERSISTENT_6X6=1 adds their rows when such a build is under test.
+# The persistent-wave (mode 0) kernels exist in development builds only (-DQC_PERSISTENT_6X6=1; no default handle can launch
+# one - 6x6 forms since round 2, the one-lane dense form since round 5): QC_TEST_PERSISTENT_6X6=1 adds their rows when such a
+# build is under test.
 PERSISTENT_6X6 = os.environ.get("QC_TEST_PERSISTENT_6X6") == "1"
 CASES = []
 for form in ("uniform", "general"):
@@ -31,9 +32,10 @@ for form in ("uniform", "general"):
     CASES += [(form, 1, 3, dict(group=1, pair=1), 8200 + 64 + 13)]  # paired waves: 65 workgroups, the last one with a ragged second wave
     if PERSISTENT_6X6:
         CASES += [(form, 1, 0, dict(group=1, chunk=256), 8192), (form, 2, 0, dict(group=2, chunk=256), 8192), (form, 4, 0, dict(group=4, chunk=128), 8192)]
+if PERSISTENT_6X6:
+    CASES += [("dense", 1, 0, dict(group=1, chunk=256), 8192)]
 CASES += [("uniform", 4, 2, dict(group=4, one_fill=1, race=0), 8192),
-          ("dense", 1, 0, dict(group=1, chunk=256), 8192),
-          ("dense", 1, 1, dict(group=1, one_fill=1), 8192),
+          ("dense", 1, 1, dict(group=1, one_fill=1), 8200),  # ragged; the Hessian planes are the workgroup's only LDS (output stock aliased)
           ("dense", 4, 1, dict(group=4, race=0), 8192)]
 IDS = [f"{f}-G{g}-mode{m}" for f, g, m, _, _ in CASES]
 
