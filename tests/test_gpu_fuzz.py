@@ -45,6 +45,17 @@ def test_planner_fuzz_20s(built):
     assert done >= 2 and state_mismatch_ticks == 0 and worst_tau < 1e-6 and worst_p < 1e-9, (worst_tau, worst_p, state_mismatch_ticks, done)
 
 
+def test_gait_clock_fuzz_20s(built):
+    """random gait periods (qc_set_gait) and jittered gait_dt over hundreds of ticks, with a quarter of the
+    steps aimed at the duty edge's 1e-12 slack (gait.cpp:125-134), the phase wrap and dt = 0 / whole periods: the clock the device
+    carries stays bit-equal to the oracle's GaitScheduler::update, and contact states, swing state and torques follow."""
+    from tests import stress_fuzz_gait
+
+    worst_tau, mismatch_ticks, edges, aimed_hits, done = stress_fuzz_gait.run_campaign(runs=30, n=1024, ticks=500, budget_s=20.0)
+    assert done >= 1 and mismatch_ticks == 0 and worst_tau < 1e-6, (worst_tau, mismatch_ticks, done)
+    assert edges > 1000 and aimed_hits > 1000, (edges, aimed_hits)  # the campaign really exercised edges and the slack
+
+
 def test_cross_form_parity_600k(built):
     """tests/stress_parity.py under pytest: every formulation and lane-group width on the same 600 000 robots - the default
     plan (paired waves at this size), one-fill workgroups (pair = 0), four lanes per robot, the general 6x6 and the dense
