@@ -952,47 +952,8 @@ QC_DEV int clamp_steps_for(CParams& P, const uint32_t* warm) {
 // MODE 0: persistent waves (chunks of many fills, lane refill).  MODE 1: the launch gives every wave at most one
 // fill (chunk <= 64 / G).  MODE 2: one fill and the SIMD to itself, recalculation constants resident in VGPRs.
 // RACE (strided 4-lane one-fill kernels): strategies racing per robot, 1, 2 or 4; a wave then holds 16 / RACE robots (see Lane).
-#ifdef QC_EXPERIMENT_SPLIT_FILL
-// EXPERIMENT: the fill / assemble role as a kernel of its own (few registers: 3+ waves per SIMD), which either
-// stores like the batch-load probe (WHAT = 0) or parks every robot's assembled record - 6 b, 12 r, the flag word, 9 Rwb: 28
-// planes [plane][n] - for a solve kernel that starts from coalesced 512-byte loads (WHAT = 1).  The record pointer travels in
-// BatchIn::joint_qdot, which the non-KIN kernels never read.
-constexpr int REC_PLANES = 28;
-template <int MINW, int WHAT>
-__global__ __launch_bounds__(64, MINW) void fill_role_kernel(const DevParams* __restrict__ Pg, const long n, const BatchIn in,
-                                                             const uint32_t* __restrict__ warm, const BatchOut out) {
-  const long robot = (long)blockIdx.x * 64 + threadIdx.x;
-  if (robot >= n) return;
-  const uint32_t sw = in.stance ? *reinterpret_cast<const uint32_t*>(in.stance + 4 * robot) : 0u;
-  const uint32_t wv = warm ? warm[robot] : 0u;
-  RawState S;
-  TickExtra X;
-  double fp[12];
-  fetch_extra<false>(in, robot, X);
-  fetch_state<4, false>(in, robot, 0, S, fp);
-  asm volatile("" ::: "memory");
-  CParams& P = *QC_PARAMS_HERE(Pg);
-  Wrench<4> W;
-  const uint32_t st = assemble_from_state<false, 4, false>(P, in, robot, 0, S, fp, sw, X, W);
-  if constexpr (WHAT == 0) {
-    const double fw[12] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    store_result<false, 4>(P, in, out, robot, st, QC_MAX_ITER, 0, 0u, fw, 0);
-  } else {
-    double* __restrict__ rec = const_cast<double*>(in.joint_qdot) + robot;
-#pragma unroll
-    for (int k = 0; k < 6; k++) rec[k * n] = W.b[k];
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-      for (int k = 0; k < 3; k++) rec[(6 + 3 * i + k) * n] = W.r[i][k];
-    rec[18 * n] = __longlong_as_double((long long)(((unsigned long long)wv << 32) | st));
-#pragma unroll
-    for (int k = 0; k < 9; k++) rec[(19 + k) * n] = S.R[k];
-  }
-}
-#endif
 
-template <class Eqp, bool KIN, int MIN_WAVES_PER_SIMD, int MODE = 0, int RACE = 1, bool REC = false>
+template <class Eqp, bool KIN, int MIN_WAVES_PER_SIMD, int MODE = 0, int RACE = 1>
 __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const DevParams* __restrict__ Pg, const long n, const BatchIn in,
                                                                          const uint32_t* __restrict__ warm, const BatchOut out, const long chunk,
                                                                          const int refill_t) {
@@ -1041,29 +1002,6 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
     if constexpr (DIRECT) {
       const long left = end - cursor;
       stock_n = left < 64 ? (int)left : 64;
-#ifdef QC_EXPERIMENT_SPLIT_FILL
-      if constexpr (REC) {
-        if (lane < stock_n) {
-          const long robot = cursor + lane;
-          const double* __restrict__ rec = in.joint_qdot + robot;
-          double v[REC_PLANES];
-#pragma unroll
-          for (int k = 0; k < REC_PLANES; k++) v[k] = rec[k * n];
-          asm volatile("" ::: "memory");
-          Wrench<4> W;
-#pragma unroll
-          for (int k = 0; k < 6; k++) W.b[k] = v[k];
-#pragma unroll
-          for (int i = 0; i < 4; i++)
-#pragma unroll
-            for (int k = 0; k < 3; k++) W.r[i][k] = v[6 + 3 * i + k];
-          const unsigned long long fl = (unsigned long long)__double_as_longlong(v[18]);
-#pragma unroll
-          for (int k = 0; k < 9; k++) sin[k * SP + lane] = v[19 + k];
-          L.load_direct(W, (uint32_t)fl, (uint32_t)(fl >> 32), robot, 0);
-        }
-      } else
-#endif
       if (lane < stock_n) {
         // Everything the fill reads from memory is issued back to back - the contact bytes and the warm-start word first
         // (behind wave-uniform null tests), then the 48 doubles of the state - and nothing dependent sits in between: a
@@ -1597,12 +1535,6 @@ struct qc_handle {
   int pair_th;        // hand-over threshold (0: heuristic)
   int pair_refill;    // free lane groups that trigger a refill (0: heuristic)
   int pair_solo;      // 1: the last round of workgroups keeps each wave's stragglers in the wave (default), 0: pairs everywhere
-#ifdef QC_EXPERIMENT_SPLIT_FILL
-  int exp_split;      // 0 off; 1 fill kernel + record-fed solve kernel; 2 fill kernel alone, storing like the batch-load probe
-  int exp_fill_minw;  // waves per SIMD the fill kernel is compiled for (1 = whatever its registers allow)
-  double* exp_rec;
-  size_t exp_rec_doubles;
-#endif
 };
 
 #define QC_COMMA(...) __VA_ARGS__
@@ -2155,10 +2087,6 @@ int qc_set_tuning(qc_handle* h, const char* key, double value) {
     // measurement probe: load -> assemble -> store only (every robot reports QC_MAX_ITER); 0 restores the handle's own cap
     h->probing = value != 0;
     h->dp.max_iter = h->probing ? 0 : h->cfg_max_iter; params = true;
-#ifdef QC_EXPERIMENT_SPLIT_FILL
-  } else if (k == "split_fill") { h->exp_split = (int)value;
-  } else if (k == "fill_minw") { h->exp_fill_minw = (int)value;
-#endif
   } else return fail(QC_ERR_INVALID, "qc_set_tuning: unknown key '" + k + "'");
   return params ? upload_params(h) : QC_OK;
 }
@@ -2220,31 +2148,6 @@ int qc_control_batch(qc_handle* h, size_t n, const qc_batch_in* in, const uint32
     QC_HIP(hipGetLastError());
     return QC_OK;
   }
-#ifdef QC_EXPERIMENT_SPLIT_FILL
-  if (h->exp_split && !kin && h->diag_w && h->uniform && lp.G == 1 && lp.mode == 1) {
-    using namespace qc;
-    typedef void (*fill_fn)(const DevParams*, long, BatchIn, const uint32_t*, BatchOut);
-    const int mw = h->exp_fill_minw;
-    const bool rec = h->exp_split == 1;
-#define QC_FILL(M) (rec ? (fill_fn)fill_role_kernel<M, 1> : (fill_fn)fill_role_kernel<M, 0>)
-    const fill_fn ff = mw >= 8 ? QC_FILL(8) : (mw >= 6 ? QC_FILL(6) : (mw >= 4 ? QC_FILL(4) : (mw == 3 ? QC_FILL(3) : (mw == 2 ? QC_FILL(2) : QC_FILL(1)))));
-#undef QC_FILL
-    if (rec && h->exp_rec_doubles < (size_t)REC_PLANES * n) {
-      if (h->exp_rec) QC_HIP(hipFree(h->exp_rec));
-      QC_HIP(hipMalloc((void**)&h->exp_rec, (size_t)REC_PLANES * n * sizeof(double)));
-      h->exp_rec_doubles = (size_t)REC_PLANES * n;
-    }
-    BatchIn b2 = bi;
-    b2.joint_qdot = h->exp_rec;
-    ff<<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream>>>(h->d_params, (long)n, b2, warm, bo);
-    QC_HIP(hipGetLastError());
-    if (!rec) return QC_OK;
-    qc_kernel_fn sf = (qc_kernel_fn)balance_kernel<EqpDiagW<true, 1>, false, 2, 1, 1, true>;
-    sf<<<dim3(lp.blocks), dim3(64), lp.lds, (hipStream_t)stream>>>(h->d_params, (long)n, b2, warm, bo, lp.chunk, lp.refill_t);
-    QC_HIP(hipGetLastError());
-    return QC_OK;
-  }
-#endif
   lp.fn<<<dim3(lp.blocks), dim3(64), lp.lds, (hipStream_t)stream>>>(h->d_params, (long)n, bi, warm, bo, lp.chunk, lp.refill_t);
   QC_HIP(hipGetLastError());
   return QC_OK;

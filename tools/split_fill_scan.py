@@ -75,7 +75,7 @@ for name, kind, n in (("cfg5s", "cold", 262144), ("cfg4", "warm", 262144), ("2M"
         solved = int((sets[0][2]["status"] == 0).sum())
         note = ""
         if tune.get("probe_batch_load") or tune.get("split_fill") == 2:
-            note = f"   [{488 * n / best / 1e6:.0f} GB/s = {488 * n / best / 1e6 / 80:.1f} % of HBM peak]"
+            note = f"   [{488 * n / best / 1e3:.0f} GB/s = {488 * n / best / 1e3 / 80:.1f} % of HBM peak]"
         else:
             assert solved == n, (label, solved)
             if ref is None: ref = g.clone()
