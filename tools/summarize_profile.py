@@ -55,12 +55,16 @@ if os.path.exists(bl) and os.path.getsize(bl):
 if "SQ_INSTS_VALU" in counters and krows and "bench_line" in out:
     main = max(krows, key=lambda r: float(r["TotalDurationNs"]))
     robots = out["bench_line"]["config"]["robots_per_gpu"]
-    kernel_ns = float(out["bench_line"]["roofline"]["avg_kernel_us"]) * 1e3  # HIP-event average of the timed launches
+    # the kernel's own average duration (rocprofv3 --kernel-trace --stats): what the per-launch counters belong to.  Rounds 2-4 used
+    # the bench line's HIP-event average here, which also holds the gaps between launches - under the profiler those can be large
+    # (round 5's config-3 pass: 55.9 us per step by HIP events around 34.9 us kernels)
+    kernel_ns = float(main["AverageNs"])
     cycles = kernel_ns * 2.4
     out["valu"] = {"insts_valu_per_launch": counters["SQ_INSTS_VALU"], "insts_valu_per_robot": counters["SQ_INSTS_VALU"] * 64.0 / robots / 64.0 * 64.0 / 64.0,
                    "wave_insts_per_wave": counters["SQ_INSTS_VALU"] / counters["SQ_WAVES"] if counters.get("SQ_WAVES") else None,
                    "issue_frac": counters["SQ_INSTS_VALU"] * 4.0 / (1024.0 * cycles), "simds": 1024, "clock_ghz": 2.4, "cycles_per_wave_inst": 4,
-                   "kernel_ns": kernel_ns, "rocprof_avg_ns": float(main["AverageNs"])}
+                   "kernel_ns": kernel_ns, "rocprof_avg_ns": float(main["AverageNs"]),
+                   "bench_event_ns": float(out["bench_line"]["roofline"]["avg_kernel_us"]) * 1e3}
     out["valu"]["insts_valu_per_robot"] = counters["SQ_INSTS_VALU"] / robots  # wave-instructions per robot (a wave-instruction serves up to 64 lanes)
     # mean resident waves per SIMD over the launch: SQ_WAVE_CYCLES (quad-cycles a wave is resident, summed over waves; the SQ_* cycle
     # counters tick once per four clocks, MI355X_MICROARCH.md) / (1024 SIMDs x the launch's quad-cycles)
