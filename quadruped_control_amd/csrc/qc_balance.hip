@@ -399,7 +399,10 @@ QC_DEV uint32_t assemble_from_state(CParams& P, const BatchIn& in, long robot, i
       double* wp = in.gait_phase + 4 * robot;
 #pragma unroll
       for (int i = 0; i < 4; i++) {
-        phs[i] = fmod(phs[i] + step, 1.0);
+        // fmod(v, 1.0), bit for bit, without the library's division loop (four of them per robot were ~2 us of a wave's fill): the
+        // integer part of a double subtracts exactly, and fmod's result carries the sign of v (-1.0 -> -0.0; inf -> NaN both ways)
+        const double v = phs[i] + step;
+        phs[i] = __builtin_copysign(v - __builtin_trunc(v), v);
         // every lane of the group computes the same four values; the first one stores them (read again, past
         // the vector L1, by this wave's store phase for the swing trajectories)
         if (member == 0) __hip_atomic_store(wp + i, phs[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

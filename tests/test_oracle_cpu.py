@@ -463,3 +463,21 @@ def test_reference_inside_the_inner_reach_limit_gives_nan_torques():
         assert np.isfinite(qr[0]) and np.isnan(qr[1]) and np.isnan(qr[2])
         tau = O.swing_torque(leg, np.eye(3), np.zeros(3), target, np.array([0.1, 0.2, -0.1]), np.zeros(3), np.zeros(3), kin)
         assert np.isnan(tau).all(), tau
+
+
+def test_gait_clock_wrap_is_fmod_bit_for_bit():
+    """The device wraps its gait phases with copysign(v - trunc(v), v) instead of calling fmod(v, 1.0) (qc_balance.hip,
+    assemble_from_state; GaitScheduler::update, gait.cpp:113-123 uses fmod): the two are the same function bit for bit - the
+    integer part of a double subtracts exactly and fmod's result carries its argument's sign - on phases, negative steps,
+    exact integers (fmod(-1.0, 1) = -0.0), neighbours of integers, subnormals, huge values, infinities and NaN."""
+    rng = np.random.default_rng(12)
+    parts = [rng.uniform(0, 2, 400000), rng.uniform(-3, 4, 400000), rng.uniform(0, 1000, 100000),
+             np.arange(-5, 6, dtype=np.float64), np.nextafter(np.arange(-5, 6, dtype=np.float64), 10.0), np.nextafter(np.arange(-5, 6, dtype=np.float64), -10.0),
+             rng.integers(0, 2**63, 400000, dtype=np.uint64).view(np.float64), rng.integers(0, 2**63, 400000, dtype=np.uint64).view(np.float64) * -1.0,
+             np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 5e-324, -5e-324, 1 - 2.0**-53, 2.0**52 + 0.5, 2.0**53, 1e308])]
+    v = np.concatenate(parts)
+    with np.errstate(all="ignore"):
+        a = np.fmod(v, 1.0)
+        b = np.copysign(v - np.trunc(v), v)
+    same = (a.view(np.uint64) == b.view(np.uint64)) | (np.isnan(a) & np.isnan(b))
+    assert same.all(), v[~same][:10]
