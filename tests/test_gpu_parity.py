@@ -92,3 +92,44 @@ def test_single_robot_control_kat1(q):
     assert abs(fm["RL"][2] + 35.0705746471) < 1e-8
     with pytest.raises(KeyError):
         ctl.control(I, I, x, z, z, x, z, z, {"RL": [0, 0, 0]})
+
+
+def test_complete_tick_golden(q):
+    """tests/golden/tick_golden.json: the complete controller tick over a trot and a walk, 30 jittered ticks each, written by the
+    numpy restatement of commander_node.cpp:383-531 (oracle/tick_restatement.py) and cross-checked against the C oracle when it was
+    made.  The device - gait clock, contact rule, foothold planner, sextic trajectories, IK / pinv, joint PD, QP, J^T in one launch per
+    tick, state carried in qc_swing_state - reproduces every tick: clock bit for bit, contact states and trajectory flags, forces and
+    torques to 1e-6.  (Device pointers and host pointers, the two entry points a caller has.)"""
+    import torch
+
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "tick_golden.json")))
+    for case in gold["cases"]:
+        P = q.cheetah_params(case["mu"])
+        base = {k: np.ascontiguousarray(np.array(v, dtype=np.float64)) for k, v in case["inputs"].items()}
+        n = base["Rwb"].shape[0]
+        for entry in ("host", "device"):
+            ctl = q.BalanceController.from_params(P)
+            ctl.set_gait(case["t_swing"], case["t_stance"])
+            phase = np.ascontiguousarray(np.array(case["phase0"]))
+            state = q.new_swing_states(n)
+            if entry == "device":
+                d_phase = torch.from_numpy(phase).cuda()
+                d_state = torch.from_numpy(state.view("uint8").reshape(-1).copy()).cuda()
+                d_base = q.to_device(base)
+            for t in case["ticks"]:
+                x, dt = np.ascontiguousarray(np.array(t["x"])), np.ascontiguousarray(np.array(t["dt"]))
+                if entry == "host":
+                    o = ctl.control_batch_host(dict(base, x=x, gait_phase=phase, gait_dt=dt, swing_state=state), want_torques=True)
+                    ph, st, grf, tau, status = phase, state, o["grf_body"], o["joint_tau"], o["status"]
+                else:
+                    o = ctl.control_batch(dict(d_base, x=torch.from_numpy(x).cuda(), gait_phase=d_phase, gait_dt=torch.from_numpy(dt).cuda(), swing_state=d_state),
+                                          want_torques=True)
+                    torch.cuda.synchronize()
+                    ph = d_phase.cpu().numpy()
+                    st = d_state.cpu().numpy().view(state.dtype)
+                    grf, tau, status = o["grf_body"].cpu().numpy(), o["joint_tau"].cpu().numpy(), o["status"].cpu().numpy()
+                assert np.array_equal(ph, np.array(t["phase"]))  # GaitScheduler::update on the device, bit for bit
+                assert (status == 0).all()
+                assert np.array_equal(st["leg_state"], np.array(t["leg_state"])) and np.array_equal(st["has_traj"], np.array(t["has_traj"]))
+                assert _relerr(grf, np.array(t["grf_body"])) < RTOL
+                assert np.abs(tau - np.array(t["joint_tau"])).max() < 1e-6 * 20.0

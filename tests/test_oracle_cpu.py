@@ -12,6 +12,8 @@ from oracle import c_oracle as O
 from oracle import numpy_restatement as R
 from quadruped_control_amd import workloads as W
 
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "balance_golden.json")
 FIELDS = ("Rwb", "Rwb_d", "x", "xdot", "w", "x_d", "xdot_d", "w_d", "feet")
 
@@ -481,3 +483,90 @@ def test_gait_clock_wrap_is_fmod_bit_for_bit():
         b = np.copysign(v - np.trunc(v), v)
     same = (a.view(np.uint64) == b.view(np.uint64)) | (np.isnan(a) & np.isnan(b))
     assert same.all(), v[~same][:10]
+
+
+def test_tick_restatement_matches_the_c_oracle_over_a_gait():
+    """The tick AROUND the QP - gait clock, contact rule, foothold planner, sextic trajectories, IK, Jacobian inverse, joint PD,
+    J^T, merge and clamp (commander_node.cpp:383-531) - restated twice: oracle/balance_oracle.c (flat arrays, per-trajectory Gaussian
+    solve, Jacobi SVD) and oracle/tick_restatement.py (the reference's own maps and classes, numpy's solve / SVD, NNLS for the QP).
+    Only FK and the Jacobian are pinned by reference-held numbers (the notebook); for everything else the two restatements hold
+    each other: same contact states and trajectories tick by tick, footholds to 1e-12, torques to 1e-6 of tau_max, over a trot and a
+    walk with jittered time steps, stretched legs (out-of-reach references: the pinv branch) included."""
+    from oracle import tick_restatement as T
+
+    kin = O.default_kinematics()
+    # the constants each side took from the reference agree
+    assert np.allclose(np.array(kin.hip).reshape(4, 3), [T.LINK_MAP[l][0] for l in T.LEGS]) and np.allclose(np.array(kin.links).reshape(4, 3), [T.LINK_MAP[l][1] for l in T.LEGS])
+    assert np.allclose(np.array(kin.planner_hip).reshape(4, 3), [T.HIP_MAP[l] for l in T.LEGS]) and kin.planner_k == T.PLANNER_K
+    assert (kin.t_swing, kin.t_stance, kin.swing_height, kin.tau_min, kin.tau_max) == (0.18, 0.8, 0.08, -20.0, 20.0)
+    P = R.cheetah_params(0.6)
+    rng = np.random.default_rng(21)
+    n, ticks = 24, 90
+    saw = dict(edges=0, pinv=0, swing_torque=0)
+    for offs, (t_sw, t_st) in (((0.0, 0.5, 0.5, 0.0), (0.18, 0.8)), ((0.0, 0.25, 0.5, 0.75), (0.3, 0.3))):
+        kin.t_swing, kin.t_stance = t_sw, t_st
+        base = W.with_swing_references(W.with_joint_angles(W.config3(n, seed=int(rng.integers(1, 2**31)))))
+        base = {k: v for k, v in base.items() if k not in ("stance", "swing_pos", "swing_vel")}
+        base["joint_q"][::5] += rng.uniform(-0.6, 0.6, (len(base["joint_q"][::5]), 12))  # some far-from-nominal postures
+        base["xdot"][1::4, :2] *= 8.0  # fast robots: the Raibert + LIP foothold lands out of reach, IK clamps d = 1, the Jacobian is singular
+        phases = np.ascontiguousarray(np.fmod(np.array(offs)[None] + rng.uniform(0, 1, (n, 1)), 1.0))
+        states = O.new_swing_states(n)
+        robots = [T.Commander(P, phases[i], t_swing=t_sw, t_stance=t_st) for i in range(n)]
+        for tick in range(ticks):
+            dt = np.ascontiguousarray(rng.uniform(0.0, 0.02, n))
+            b = dict(base)
+            b["x"] = np.ascontiguousarray(base["x"] + 0.003 * tick * base["xdot"])  # drift: footholds and out-of-reach references change
+            O.gait_update(phases, dt, kin=kin)
+            prev = states["leg_state"].copy()
+            ref = O.tick_planned_batch(P, dict(b, gait_phase=phases), states, kin=kin)
+            saw["edges"] += int(((prev == 1) & (states["leg_state"] == 0)).sum())
+            for i in range(n):
+                tau, grf, status, st = robots[i].tick(b["Rwb"][i], b["Rwb_d"][i], b["x"][i], b["xdot"][i], b["w"][i], b["x_d"][i], b["xdot_d"][i], b["w_d"][i],
+                                                      b["joint_q"][i], b["joint_qdot"][i], dt=dt[i])
+                assert np.array_equal(robots[i].gait.phases, phases[i])  # the same clock, bit for bit
+                assert status == ref["status"][i] == 0
+                assert st["leg_state"] == list(states["leg_state"][i]) and st["has_traj"] == list(states["has_traj"][i]), (tick, i)
+                for leg, (p0, pf) in st["bounds"].items():
+                    k = T.LEGS.index(leg)
+                    for mine, theirs in ((p0, states["p_start"][i, 3 * k:3 * k + 3]), (pf, states["p_final"][i, 3 * k:3 * k + 3])):
+                        assert np.array_equal(np.isnan(mine), np.isnan(theirs)) and np.nanmax(np.abs(mine - theirs), initial=0.0) < 1e-12
+                assert np.abs(grf - ref["grf_body"][i]).max() < 1e-6 * max(1.0, np.abs(grf).max())
+                assert np.array_equal(np.isnan(tau), np.isnan(ref["joint_tau"][i]))
+                assert np.nanmax(np.abs(tau - ref["joint_tau"][i]), initial=0.0) < 1e-6 * 20.0, (tick, i, tau, ref["joint_tau"][i])
+                sw = [k for k in range(4) if st["leg_state"][k] == 0]
+                saw["swing_torque"] += len(sw)
+                for k in sw:  # how often the stretched-leg branch answered
+                    pos, vel = robots[i].trajectories.reference_state(T.LEGS[k], phases[i, k])
+                    qr = T.leg_inverse_kinematics(T.LEGS[k], b["Rwb"][i].reshape(3, 3).T @ pos - b["x"][i])
+                    saw["pinv"] += int(qr[2] == 0.0)
+    assert saw["edges"] > 100 and saw["swing_torque"] > 1000 and saw["pinv"] > 10, saw
+
+
+def _tick_golden():
+    import json
+
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "tick_golden.json")))
+
+
+def test_c_oracle_matches_tick_golden():
+    """tests/golden/tick_golden.json (written by the numpy restatement of the complete tick, tests/golden/make_tick_golden.py): the C
+    oracle reproduces every tick - clock bit for bit, contact states and trajectories, forces and torques to 1e-6."""
+    gold = _tick_golden()
+    assert gold["leg_order"] == ["RL", "FL", "RR", "FR"] and len(gold["cases"]) == 2
+    for case in gold["cases"]:
+        P = R.cheetah_params(case["mu"])
+        kin = O.default_kinematics()
+        kin.t_swing, kin.t_stance = case["t_swing"], case["t_stance"]
+        base = {k: np.ascontiguousarray(np.array(v, dtype=np.float64)) for k, v in case["inputs"].items()}
+        n = base["Rwb"].shape[0]
+        phases = np.ascontiguousarray(np.array(case["phase0"]))
+        states = O.new_swing_states(n)
+        for t in case["ticks"]:
+            O.gait_update(phases, np.ascontiguousarray(np.array(t["dt"])), kin=kin)
+            assert np.array_equal(phases, np.array(t["phase"]))
+            r = O.tick_planned_batch(P, dict(base, x=np.ascontiguousarray(np.array(t["x"])), gait_phase=phases), states, kin=kin)
+            assert (r["status"] == 0).all()
+            assert np.array_equal(states["leg_state"], np.array(t["leg_state"])) and np.array_equal(states["has_traj"], np.array(t["has_traj"]))
+            g = np.array(t["grf_body"])
+            assert np.abs(r["grf_body"] - g).max() < 1e-6 * max(1.0, np.abs(g).max())
+            assert np.abs(r["joint_tau"] - np.array(t["joint_tau"])).max() < 1e-6 * 20.0
