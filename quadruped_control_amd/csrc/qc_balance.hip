@@ -81,7 +81,8 @@ struct Lane {
   // multiplier test on the current face: true if all active faces have
   // lambda >= -tol; otherwise wcode = 3*foot+axis of the most negative one.
   template <class PT>
-  QC_DEV bool multipliers_ok(const PT& P, const double (&g)[3 * FPL], int& wcode, bool (&neg)[3 * FPL]) const {
+  QC_DEV bool multipliers_ok(const PT& P, const double (&g)[3 * FPL], int& wcode, bool (&neg)[3 * FPL], uint32_t& negbits) const {
+    negbits = 0u;
     double gs = 1.0;
 #pragma unroll
     for (int k = 0; k < 3 * FPL; k++) gs = max_abs_nn(gs, g[k]);
@@ -101,6 +102,13 @@ struct Lane {
         neg[3 * i + 0] = (C.sx[i] != 0) & (lx < thr);
         neg[3 * i + 1] = (C.sy[i] != 0) & (ly < thr);
         neg[3 * i + 2] = (C.sz[i] != 0) & (lz < thr);
+        if constexpr (FPL == 4) {
+          // one lane per robot (the dense form's twin race): twelve lane masks = twelve SGPR pairs across the state update, next to a
+          // kernel whose pointers already fill half of the SGPR file - they spill, and SGPR pairs that spill leave frame slots.
+          // The same twelve answers as bits of one VGPR (negbits); the bool array is dead on this path.
+          negbits |= (neg[3 * i + 0] ? 1u : 0u) << (3 * i) | (neg[3 * i + 1] ? 2u : 0u) << (3 * i) | (neg[3 * i + 2] ? 4u : 0u) << (3 * i);
+          neg[3 * i + 0] = neg[3 * i + 1] = neg[3 * i + 2] = false;
+        }
       } else {
         neg[3 * i + 0] = neg[3 * i + 1] = neg[3 * i + 2] = false;
       }
@@ -207,7 +215,9 @@ struct Lane {
 #pragma unroll
     for (int k = 0; k < 3 * FPL; k++) neg[k] = false;
     bool opt = true;
-    if (!(PHASE == FIRST && empty_set)) opt = multipliers_ok(P, g, wcode, neg);
+    uint32_t negbits = 0u;  // (FPL == 4 && RACE: `neg` as bits of one register)
+    if (!(PHASE == FIRST && empty_set)) opt = multipliers_ok(P, g, wcode, neg, negbits);
+    if constexpr (RACE && FPL == 4) asm volatile("" : "+v"(negbits));
     if (!at_fh) wcode = -1;
     const bool dall = RACE & drop_all & at_fh;  // this lane's strategy drops every negative multiplier at once
     const bool take_clamp = fresh & changed;
@@ -215,9 +225,12 @@ struct Lane {
     for (int i = 0; i < FPL; i++) {
       int sx = C.sx[i], sy = C.sy[i], sz = C.sz[i];
       const int b0 = 6 * (foot0 + i), w0 = 3 * (foot0 + i);
-      const bool px = RACE ? (dall ? neg[3 * i + 0] : wcode == w0 + 0) : wcode == w0 + 0;
-      const bool py = RACE ? (dall ? neg[3 * i + 1] : wcode == w0 + 1) : wcode == w0 + 1;
-      const bool pz = RACE ? (dall ? neg[3 * i + 2] : wcode == w0 + 2) : wcode == w0 + 2;
+      const bool nx = (RACE && FPL == 4) ? ((negbits >> (3 * i)) & 1u) != 0 : neg[3 * i + 0];
+      const bool ny = (RACE && FPL == 4) ? ((negbits >> (3 * i + 1)) & 1u) != 0 : neg[3 * i + 1];
+      const bool nz = (RACE && FPL == 4) ? ((negbits >> (3 * i + 2)) & 1u) != 0 : neg[3 * i + 2];
+      const bool px = RACE ? (dall ? nx : wcode == w0 + 0) : wcode == w0 + 0;
+      const bool py = RACE ? (dall ? ny : wcode == w0 + 1) : wcode == w0 + 1;
+      const bool pz = RACE ? (dall ? nz : wcode == w0 + 2) : wcode == w0 + 2;
       sx = (bcode == b0 + 0) ? -1 : ((bcode == b0 + 1) ? 1 : (px ? 0 : sx));
       sy = (bcode == b0 + 2) ? -1 : ((bcode == b0 + 3) ? 1 : (py ? 0 : sy));
       sz = (bcode == b0 + 4) ? -1 : ((bcode == b0 + 5) ? 1 : (pz ? 0 : sz));
@@ -981,7 +994,8 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
   const int member = lane_member<G, STR>(lane);
   int stock_n = 0, stock_next = 0;  // input stock: slots [stock_next, stock_n) hold assembled robots
   int out_n = 0;                    // output stock: slots [0, out_n) hold finished results
-  Lane<Eqp, KIN, (RACE > 1)> L;
+  constexpr bool TWIN = Eqp::kHessianInLds && MODE != 0 && !KIN;  // one-lane dense form: stragglers fork into idle lanes with the other drop rule
+  Lane<Eqp, KIN, (RACE > 1) || TWIN> L;
   L.idx = -1;
   L.foot0 = member * (4 / G);
   Eqp eqp(qc_lds + (HESS_ONLY ? 0 : stock_doubles(stock_slots(G, MODE))) + lane);
@@ -1037,7 +1051,7 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
     busy = grp < stock_n;
     // measurement probe (qc_set_tuning "probe_batch_load"): load -> assemble -> store only, no recalculation
     const bool probe = QC_PARAMS_HERE(Pg)->max_iter == 0;
-    using LaneT = Lane<Eqp, KIN, (RACE > 1)>;
+    using LaneT = Lane<Eqp, KIN, (RACE > 1) || TWIN>;
     if constexpr (STR) {
       // Strided layout: the group sums run on the matrix pipe, and an MFMA reads its operands from ALL 64 lanes
       // whatever EXEC says - the all-ones A operand included, which the compiler materialises under the current
@@ -1162,6 +1176,121 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
       }
       if (!busy && mine) L.template push_result<SP>(sout, grp);  // finished in the two-lane layout
       finish_on_four_lanes<KIN, Eqp::kUniform, SP>(Pg, L, busy, bm, grp, member, lane, sin + R_PLANES * SP, sout, warm == nullptr);
+    } else if constexpr (TWIN) {
+      // The one-lane dense form has no 4-lane tail (the exchange tile of the 4-lane dense body does not fit next to the Hessian
+      // planes), so a wave walks its one-lane body until its slowest robot is done - at half the lanes or fewer busy for most of
+      // that walk.  Those idle lanes race: once at most 32 robots still run, every running robot is copied into an idle lane
+      // (working set, point, c, its 78 Hessian entries from the owner's LDS column to the twin's) which continues with the OTHER
+      // drop rule - all negative multipliers at once instead of the most negative one - and whoever reaches the KKT point first
+      // ends both (the tail race of the 6x6 forms, profiles/r02_tail_race_scan.log, with lanes instead of lane groups).  Cold
+      // batches only: a warm-started robot that is not done after its first recalculation is a face or two away.
+      unsigned long long bm = __builtin_amdgcn_ballot_w64(busy);
+      const bool fork_ok = warm == nullptr && QC_PARAMS_HERE(Pg)->tail_race != 0;
+      // (both loops are wave-uniform and run every lane with `live` = busy - see Lane::iterate on why a finished or empty lane may
+      // keep computing: a per-lane branch around the 2 600-instruction body costs exec-mask saves in SGPR pairs, which spill here)
+      while (__builtin_popcountll(bm) > (fork_ok ? 32 : 0)) {
+        const bool done = L.template iterate<LaneT::STEADY>(*QC_PARAMS_HERE(Pg), eqp, busy);
+        busy = busy & !done;
+        bm = __builtin_amdgcn_ballot_w64(busy);
+      }
+      int partner = lane;   // the lane racing on the same robot (itself: no race)
+      // per-lane flags of the race, packed into one VGPR (as separate bools they live in SGPR pairs across the 2 600-instruction
+      // body, and SGPR pairs that spill leave frame slots): bit 0 this lane still holds a result (its own robot's) that has to
+      // reach the output, bit 1 it is a twin, bit 2 it brought its robot to the KKT point
+      int role = mine ? 1 : 0;
+      if (bm != 0) {
+        // lanes whose own robot is finished store it straight from their registers (the output stock aliases Hessian planes that
+        // are still being read; Rwb comes from memory) - their registers are about to carry somebody else's robot
+        if (mine && !busy) {
+          CParams& P = *QC_PARAMS_HERE(Pg);
+          store_result<KIN, 4, false>(P, in, out, L.idx, L.stance, L.status, L.iters, L.word_bits() | 0x80000000u, L.f, 0);
+          role = 0;
+        }
+        const int nb = __builtin_popcountll(bm);
+        const unsigned long long idle = ~bm;
+        const int my_rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)((busy ? bm : idle) >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)(busy ? bm : idle), 0));
+        // lane id of the rank-th set bit of m (ranks from 0; m has more than `rank` bits set): binary search on popcounts
+        auto nth = [](unsigned long long m, int rank) {
+          int pos = 0;
+#pragma unroll
+          for (int w = 32; w >= 1; w >>= 1) {
+            const int c = __builtin_popcountll(m & ((1ull << w) - 1ull));
+            const bool up = rank >= c;
+            m = up ? (m >> w) : m;
+            rank -= up ? c : 0;
+            pos += up ? w : 0;
+          }
+          return pos;
+        };
+        const bool twin = !busy && my_rank < nb;  // the my_rank-th idle lane takes the my_rank-th running robot
+        if (busy) partner = nth(idle, my_rank);
+        if (twin) partner = nth(bm, my_rank);
+        // the owner's state, read by its twin (every lane executes the shuffles; only twins keep what they read)
+        const int src = twin ? partner : lane;
+        auto take_i = [&](int v) { return __builtin_amdgcn_ds_bpermute(src << 2, v); };
+        auto take_d = [&](double v) {
+          const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+          const unsigned lo = (unsigned)take_i((int)(unsigned)u), hi = (unsigned)take_i((int)(unsigned)(u >> 32));
+          return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+        };
+        const uint32_t wbits = (uint32_t)take_i((int)L.word_bits());
+        const uint32_t stance_o = (uint32_t)take_i((int)L.stance);
+        const int iters_o = take_i(L.iters);
+        const int idx_lo = take_i((int)(unsigned)(unsigned long long)L.idx), idx_hi = take_i((int)(unsigned)((unsigned long long)L.idx >> 32));
+        // (one value at a time, selected in place: two dozen temporaries next to the 78-entry factor's registers would spill)
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+          const double tf = take_d(L.f[k]);
+          L.f[k] = twin ? tf : L.f[k];
+          const double tc = take_d(eqp.c[k]);
+          eqp.c[k] = twin ? tc : eqp.c[k];
+        }
+        if (twin) {
+          L.stance = stance_o;
+          L.iters = iters_o;
+          L.idx = (long)(((unsigned long long)(unsigned)idx_hi << 32) | (unsigned)idx_lo);
+          L.status = QC_MAX_ITER;
+          L.have_f = true;
+          L.drop_all = true;
+          L.foot0 = 0;
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const uint32_t fb = wbits >> (6 * i);
+            L.C.sx[i] = dec2(fb); L.C.sy[i] = dec2(fb >> 2); L.C.sz[i] = dec2(fb >> 4);
+          }
+          // the robot's Hessian: the owner's LDS column -> this lane's (the owner only reads its column from here on)
+          const double* from = eqp.Qs - lane + partner;
+#pragma unroll 6
+          for (int k = 0; k < 78; k++) eqp.Qs[k * 64] = from[k * 64];
+          role = 2;
+          busy = true;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+      asm volatile("" : "+v"(role), "+v"(partner));
+      while (__builtin_amdgcn_ballot_w64(busy) != 0) {
+        const bool done = L.template iterate<LaneT::STEADY>(*QC_PARAMS_HERE(Pg), eqp, busy);
+        asm volatile("" : "+v"(role), "+v"(partner));
+        const int solved = (busy && done && L.status == QC_SOLVED) ? 1 : 0;
+        const int fin = (busy && done) ? 1 : 0;
+        const int theirs = __builtin_amdgcn_ds_bpermute(partner << 2, solved);
+        // a tie goes to the owner (the classic rule); a twin stops as soon as its owner is finished in any way
+        const int owner_done = __builtin_amdgcn_ds_bpermute(partner << 2, fin);
+        const bool is_twin = (role & 2) != 0;
+        role |= (solved && !(is_twin && theirs)) ? 4 : 0;
+        busy = busy && !done && !(partner != lane && theirs) && !(is_twin && owner_done);
+      }
+      // who stores: the owner, unless its twin got to the KKT point first (then the twin)
+      const int twin_won = __builtin_amdgcn_ds_bpermute(partner << 2, ((role & 6) == 6) ? 1 : 0);
+      const bool store_own = (role & 1) && !(partner != lane && twin_won);
+      if (store_own || (role & 6) == 6) {  // straight from the registers, like the lanes that finished before the fork: no output stock on this path
+        CParams& P = *QC_PARAMS_HERE(Pg);
+        store_result<KIN, 4, false>(P, in, out, L.idx, L.stance, L.status, L.iters, L.word_bits() | 0x80000000u, L.f, 0);
+      }
+      QC_CLK_END(8);
+      return;
     } else {
       while (busy) {
         if constexpr (RESIDENT) {
@@ -1171,7 +1300,6 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
           busy = !L.template iterate<LaneT::STEADY>(*QC_PARAMS_HERE(Pg), eqp);
         }
       }
-      if constexpr (HESS_ONLY) __syncthreads();  // every lane is past its last read of the Hessian planes the output stock aliases
       if (mine) L.template push_result<SP>(sout, grp);
     }
     QC_CLK(7, 8);
