@@ -318,11 +318,14 @@ def test_clamp_steps_vs_oracle(q, form, G, steps):
 
 
 @pytest.mark.parametrize("start", ["cold", "warm"])
-@pytest.mark.parametrize("form,G,n", [("uniform", 1, 65536), ("uniform", 2, 20000), ("general", 1, 30011), ("general", 2, 8200)])
+@pytest.mark.parametrize("form,G,n", [("uniform", 1, 65536), ("uniform", 2, 20000), ("general", 1, 30011), ("general", 2, 8200),
+                                      ("dense", 1, 30011), ("dense", 1, 65536)])
 def test_tail_race_vs_oracle(q, form, G, n, start):
     """One / two lanes per robot with the product's defaults: the last <= 8 running robots of a wave race two drop
-    rules on the 4-lane body.  Same minimiser as the oracle, KKT-certified, never more recalculations than with the race
-    switched off, fewer for the slowest robot of a cold batch, restart from the reported working set in one."""
+    rules on the 4-lane body - and, in the one-lane dense form (round 5), every robot still running once at most 32 of a wave
+    do is copied into an idle lane that continues with the other drop rule (the twin race; 30 011 robots: a ragged last wave).
+    Same minimiser as the oracle, KKT-certified, never more recalculations than with the race switched off, fewer for the
+    slowest robot of a cold batch, restart from the reported working set in one."""
     import torch
 
     from oracle import c_oracle as O
