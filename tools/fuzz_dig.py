@@ -8,7 +8,7 @@ from oracle import c_oracle as O
 from oracle import numpy_restatement as R
 want = set(int(a) for a in sys.argv[1:]) or {48, 95, 96}
 n = int(os.environ.get("FUZZ_N", "2048"))
-rng = np.random.default_rng(77)
+rng = np.random.default_rng(int(os.environ.get("QC_FUZZ_SEED", 77)))  # the campaign whose trial is being dug out
 FIELDS = ("Rwb", "Rwb_d", "x", "xdot", "w", "x_d", "xdot_d", "w_d", "feet")
 for trial in range(max(want) + 1):
     P = q.cheetah_params(float(rng.choice([0.05, 0.2, 0.6, 1.0, 1.5])) if trial % 5 else float(rng.uniform(0.05, 2.0)))
@@ -32,6 +32,8 @@ for trial in range(max(want) + 1):
         continue
     b0 = W.config4(n, seed=seed)[0] if trial % 2 else W.config3(n, seed=seed)
     ctl = q.BalanceController.from_params(P)
+    if os.environ.get("FUZZ_TUNE"):  # e.g. FUZZ_TUNE=force_dense=1,group=4: how another formulation / width does on the same trial
+        ctl.set_tuning(**{kv.split("=")[0]: float(kv.split("=")[1]) for kv in os.environ["FUZZ_TUNE"].split(",")})
     o = ctl.control_batch_host(b0, want_active_set=True, want_iterations=True)
     ref, st, it = O.control_batch(P, b0, threads=16)
     scale = np.maximum(1.0, np.abs(ref).max(axis=1, keepdims=True))
