@@ -1300,6 +1300,7 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
           busy = !L.template iterate<LaneT::STEADY>(*QC_PARAMS_HERE(Pg), eqp);
         }
       }
+      if constexpr (HESS_ONLY) __syncthreads();  // (the dense joint_q kernel) every lane is past its last read of the Hessian planes the output stock aliases
       if (mine) L.template push_result<SP>(sout, grp);
     }
     QC_CLK(7, 8);
