@@ -285,3 +285,16 @@ def test_bench_counts_the_gait_edges_its_timed_region_contains(built):
     assert got[4] == 0.0  # the replayed clock is bit-equal to the oracle's
     # natural rate: one edge per leg per gait period
     assert abs(edges / (n * sum(per_set)) - 4 * bench.GAIT_DT / 0.98) < 0.004
+
+
+def test_development_scripts_parse():
+    """tools/, tests/stress_*.py, tests/golden/*.py and oracle/prototypes are run by hand on the GPU box, never by pytest: at least
+    every one of them must still parse (a rename in the package would otherwise rot them silently)."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "tools", "*.py")) + glob.glob(os.path.join(ROOT, "tests", "stress_*.py")) +
+                   glob.glob(os.path.join(ROOT, "tests", "golden", "*.py")) + glob.glob(os.path.join(ROOT, "oracle", "prototypes", "*.py")) +
+                   [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")])
+    assert len(files) > 60
+    for f in files:
+        compile(open(f).read(), f, "exec")  # (syntax only: nothing is imported or run, no bytecode is written)
