@@ -475,7 +475,7 @@ def test_gait_clock_wrap_is_fmod_bit_for_bit():
     rng = np.random.default_rng(12)
     parts = [rng.uniform(0, 2, 400000), rng.uniform(-3, 4, 400000), rng.uniform(0, 1000, 100000),
              np.arange(-5, 6, dtype=np.float64), np.nextafter(np.arange(-5, 6, dtype=np.float64), 10.0), np.nextafter(np.arange(-5, 6, dtype=np.float64), -10.0),
-             rng.integers(0, 2**63, 400000, dtype=np.uint64).view(np.float64), rng.integers(0, 2**63, 400000, dtype=np.uint64).view(np.float64) * -1.0,
+             rng.integers(0, 2**63, 400000, dtype=np.uint64).view(np.float64), (rng.integers(0, 2**63, 400000, dtype=np.uint64) | np.uint64(1 << 63)).view(np.float64),
              np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 5e-324, -5e-324, 1 - 2.0**-53, 2.0**52 + 0.5, 2.0**53, 1e308])]
     v = np.concatenate(parts)
     with np.errstate(all="ignore"):
