@@ -986,7 +986,16 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
   static_assert(!HESS_ONLY || (OUT_PLANES * SP + TASK_DOUBLES <= 78 * 64), "the output stock fits the Hessian planes it aliases");
   double* const sin = qc_lds;
   double* const sout = HESS_ONLY ? qc_lds : qc_lds + IN_PLANES * SP;
-  long cursor = (long)blockIdx.x * chunk;  // wave-uniform: next robot of this wave's chunk to assemble
+  // XCD-aware workgroup -> chunk map.  The dispatcher places workgroup b on XCD b % 8 (observed, MI355X_MICROARCH.md "Workgroup
+  // dispatch"; a speed assumption only - any placement computes the same robots), each XCD with an L2 of its own.  With the identity
+  // map, neighbouring chunks - which share the 128-byte lines their rows straddle: a four-robot racing wave reads 288 contiguous
+  // bytes per array - sit on different XCDs and every shared line is fetched from HBM once per XCD: 1.6x the algorithmic bytes on
+  // config 2 (profiles/r02 ... r05_cfg2).  Mapped so that each XCD walks a contiguous range of chunks (bijective for any grid size),
+  // neighbours share an L2.  (Lane-group kernels only: a one-lane wave reads 4.6 KB per array, its shared lines are 2 of 36 - counter
+  // traffic 1.00-1.03x - and the throughput kernels stay as they were measured.)
+  const unsigned nwg = gridDim.x, xcd = blockIdx.x & 7u, q8 = nwg >> 3, r8 = nwg & 7u;
+  const unsigned chunk_id = Eqp::G == 1 ? blockIdx.x : (xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+  long cursor = (long)chunk_id * chunk;  // wave-uniform: next robot of this wave's chunk to assemble
   const long end = cursor + chunk < n ? cursor + chunk : n;
   const int lane = threadIdx.x;
   constexpr bool STR = Eqp::kStrided;  // lane layout of a group (one-fill modes only)

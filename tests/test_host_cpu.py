@@ -298,3 +298,19 @@ def test_development_scripts_parse():
     assert len(files) > 60
     for f in files:
         compile(open(f).read(), f, "exec")  # (syntax only: nothing is imported or run, no bytecode is written)
+
+
+def test_xcd_aware_chunk_map_is_a_bijection():
+    """balance_kernel maps workgroup b (dispatched to XCD b % 8) to chunk (xcd < r ? xcd (q + 1) : r (q + 1) + (xcd - r) q) + b / 8 with q = grid / 8,
+    r = grid % 8, so that every XCD walks a contiguous range of chunks and neighbouring chunks - which share the cache lines their rows straddle -
+    share an L2.  The map must hit every chunk exactly once for any grid size, and keep neighbours on one XCD."""
+    src = open(os.path.join(ROOT, "quadruped_control_amd", "csrc", "qc_balance.hip")).read()
+    assert "Eqp::G == 1 ? blockIdx.x : (xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8) + (blockIdx.x >> 3)" in src
+    for nwg in list(range(1, 70)) + [255, 256, 257, 1023, 1024, 1025, 4096, 4097, 32768 + 5]:
+        b = np.arange(nwg)
+        xcd, q8, r8 = b & 7, nwg >> 3, nwg & 7
+        chunk = np.where(xcd < r8, xcd * (q8 + 1), r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3)
+        assert np.array_equal(np.sort(chunk), b), nwg
+        if nwg >= 64:
+            owner = np.empty(nwg, dtype=int); owner[chunk] = xcd
+            assert (owner[1:] != owner[:-1]).sum() <= 7  # eight contiguous ranges
