@@ -987,14 +987,25 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
   double* const sin = qc_lds;
   double* const sout = HESS_ONLY ? qc_lds : qc_lds + IN_PLANES * SP;
   // XCD-aware workgroup -> chunk map.  The dispatcher places workgroup b on XCD b % 8 (observed, MI355X_MICROARCH.md "Workgroup
-  // dispatch"; a speed assumption only - any placement computes the same robots), each XCD with an L2 of its own.  With the identity
-  // map, neighbouring chunks - which share the 128-byte lines their rows straddle: a four-robot racing wave reads 288 contiguous
-  // bytes per array - sit on different XCDs and every shared line is fetched from HBM once per XCD: 1.6x the algorithmic bytes on
-  // config 2 (profiles/r02 ... r05_cfg2).  Mapped so that each XCD walks a contiguous range of chunks (bijective for any grid size),
-  // neighbours share an L2.  (Lane-group kernels only: a one-lane wave reads 4.6 KB per array, its shared lines are 2 of 36 - counter
-  // traffic 1.00-1.03x - and the throughput kernels stay as they were measured.)
-  const unsigned nwg = gridDim.x, xcd = blockIdx.x & 7u, q8 = nwg >> 3, r8 = nwg & 7u;
-  const unsigned chunk_id = Eqp::G == 1 ? blockIdx.x : (xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+  // dispatch"; a speed assumption only - any placement computes the same robots), each XCD with an L2 of its own.  A racing wave holds
+  // 4 (or 8) robots: 288 contiguous bytes per 72-byte-row array, so neighbouring waves share the 128-byte lines their rows straddle,
+  // and with the identity map - neighbours on different XCDs - every shared line is fetched from HBM once per XCD: 1.6x the algorithmic
+  // bytes on config 2 (profiles/r02 ... r04_cfg2).  Sixteen robots are line-aligned in every array (16 x 72 B = 9 lines), so the waves
+  // of one aligned 16-robot group are mapped to ONE XCD and the groups go round the XCDs as before.  (Mapping whole contiguous eighths of
+  // the batch to an XCD removes the same re-fetches but costs config 2 0.2 us, profiles/r05_ab_xcd_map.log: the spreading of
+  // neighbouring groups over the XCDs is worth keeping.)  Waves of 16 robots or more share no line: identity.
+  unsigned chunk_id = blockIdx.x;
+#ifndef QC_NO_XCD_MAP  // (development: -DQC_NO_XCD_MAP compiles the identity map for A/B runs)
+  if constexpr (RACE > 1) {  // 16 / RACE robots per wave: RACE waves per aligned group (compile-time powers of two: shifts and masks only -
+    // with run-time divisions the map cost the wave's first 0.1 us more than it saved)
+    constexpr unsigned gw = (unsigned)RACE, super = 8u * gw;
+    const unsigned full = gridDim.x & ~(super - 1u);
+    if (blockIdx.x < full && chunk == 16 / RACE) {
+      const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+      chunk_id = (slot / gw) * super + xcd * gw + (slot % gw);
+    }
+  }
+#endif
   long cursor = (long)chunk_id * chunk;  // wave-uniform: next robot of this wave's chunk to assemble
   const long end = cursor + chunk < n ? cursor + chunk : n;
   const int lane = threadIdx.x;

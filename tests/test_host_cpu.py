@@ -301,16 +301,22 @@ def test_development_scripts_parse():
 
 
 def test_xcd_aware_chunk_map_is_a_bijection():
-    """balance_kernel maps workgroup b (dispatched to XCD b % 8) to chunk (xcd < r ? xcd (q + 1) : r (q + 1) + (xcd - r) q) + b / 8 with q = grid / 8,
-    r = grid % 8, so that every XCD walks a contiguous range of chunks and neighbouring chunks - which share the cache lines their rows straddle -
-    share an L2.  The map must hit every chunk exactly once for any grid size, and keep neighbours on one XCD."""
+    """balance_kernel's racing waves (4 or 8 robots each) share the cache lines their rows straddle with their neighbours; 16 robots are
+    line-aligned in every array.  The kernel maps workgroup b (dispatched to XCD b % 8) so that the 16 / chunk waves of an aligned group run on
+    ONE XCD (one L2 fetches the shared lines once) while the groups go round the XCDs:
+        chunk = (slot / gw) * 8 gw + xcd * gw + slot % gw,  xcd = b % 8, slot = b / 8, gw = 16 / chunk   (blocks beyond the last full 8 gw: identity).
+    The map must hit every chunk exactly once for any grid size, and keep every aligned group on one XCD."""
     src = open(os.path.join(ROOT, "quadruped_control_amd", "csrc", "qc_balance.hip")).read()
-    assert "Eqp::G == 1 ? blockIdx.x : (xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8) + (blockIdx.x >> 3)" in src
-    for nwg in list(range(1, 70)) + [255, 256, 257, 1023, 1024, 1025, 4096, 4097, 32768 + 5]:
-        b = np.arange(nwg)
-        xcd, q8, r8 = b & 7, nwg >> 3, nwg & 7
-        chunk = np.where(xcd < r8, xcd * (q8 + 1), r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3)
-        assert np.array_equal(np.sort(chunk), b), nwg
-        if nwg >= 64:
-            owner = np.empty(nwg, dtype=int); owner[chunk] = xcd
-            assert (owner[1:] != owner[:-1]).sum() <= 7  # eight contiguous ranges
+    assert "chunk_id = (slot / gw) * super + xcd * gw + (slot % gw);" in src and "constexpr unsigned gw = (unsigned)RACE, super = 8u * gw;" in src
+    for chunk in (4, 8):
+        gw = 16 // chunk
+        sup = 8 * gw
+        for nwg in list(range(1, 100)) + [255, 256, 257, 1023, 1024, 1025, 4096, 4097]:
+            b = np.arange(nwg)
+            full = (nwg // sup) * sup
+            xcd, slot = b & 7, b >> 3
+            c = np.where(b < full, (slot // gw) * sup + xcd * gw + (slot % gw), b)
+            assert np.array_equal(np.sort(c), b), (chunk, nwg)
+            owner = np.empty(nwg, dtype=int); owner[c] = xcd
+            for g in range(full // gw):  # every aligned group of gw chunks on one XCD
+                assert len(set(owner[g * gw:(g + 1) * gw])) == 1
