@@ -234,6 +234,45 @@ def test_iteration_cap_and_bad_inputs_agree_across_widths(q, cap):
     assert np.max(np.abs(r["grf_body"][ok] - ref["grf_body"][ok]) / scale) < 1e-8
 
 
+@pytest.mark.parametrize("cap", [2, 6, 7, 9, 200])
+def test_dense_twin_race_under_caps_bad_inputs_and_ragged_sizes(q, cap):
+    """Round 5: the one-lane dense kernel copies its stragglers into the wave's idle lanes (the twin continues with the other drop
+    rule; results are stored straight from registers, the lanes that finished before the fork included).  Against the same kernel
+    with the race off (race = 0): identical statuses, forces to 1e-8, never more recalculations; a recalculation cap that strikes
+    before the fork, at it or in the race, NaN / inf inputs (status 3 on either side of the fork) and batch sizes that leave a
+    ragged or a nearly empty last wave."""
+    from quadruped_control_amd import workloads as W
+
+    P = q.cheetah_params(0.6)
+    for n in (1, 31, 64, 65, 130, 5000):
+        b = W.config3(n, seed=0x5EED00A6 + n)
+        bad = np.arange(3, n, 97)
+        b["x"][bad[::2], 1] = np.nan
+        b["Rwb"][bad[1::2], 4] = np.inf
+        twin = q.BalanceController.from_params(P, max_iter=cap).set_tuning(force_dense=1, group=1, one_fill=1)
+        solo = q.BalanceController.from_params(P, max_iter=cap).set_tuning(force_dense=1, group=1, one_fill=1, race=0)
+        info = twin.query_launch(n)
+        assert (info["form"], info["lanes_per_robot"], info["mode"]) == (2, 1, 1)
+        o = twin.control_batch_host(b, want_iterations=True, want_active_set=True)
+        s_ = solo.control_batch_host(b, want_iterations=True)
+        assert (o["status"][bad] == 3).all() and np.all(o["grf_body"][bad] == 0.0)
+        good = np.setdiff1d(np.arange(n), bad)
+        # a robot the classic rule solves within the cap is solved (owner or twin, whoever is first); a capped one reports the cap
+        solved_solo = s_["status"] == 0
+        assert (o["status"][solved_solo] == 0).all()
+        assert (o["iterations"][good] <= s_["iterations"][good]).all() and (o["iterations"] <= cap).all()
+        both = (o["status"] == 0) & solved_solo
+        if both.any():
+            scale = np.maximum(1.0, np.abs(s_["grf_body"][both]).max(axis=1, keepdims=True))
+            assert np.max(np.abs(o["grf_body"][both] - s_["grf_body"][both]) / scale) < 1e-8
+        assert np.all(o["grf_body"][o["status"] != 0] == 0.0)
+        assert set(np.unique(o["status"])) <= {0, 1, 3}
+        if cap == 200:
+            assert (o["status"][good] == 0).all()
+            if n == 5000:
+                assert (o["iterations"] < s_["iterations"]).any()  # the race is in force
+
+
 @pytest.mark.parametrize("form", ["uniform", "general", "dense"])
 def test_planner_boundaries_vs_oracle(q, form):
     """Default settings at every batch size where the planner changes the kernel (racing strategies <= 4 096, four lanes
