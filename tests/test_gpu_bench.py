@@ -81,7 +81,7 @@ def test_bench_driver_line_with_the_whole_sweep(built):
     assert d["batch_load_probe"]["frac"] > 0.4  # north_star: >= 40 % of HBM peak on the batch load
     assert d["device_warmup"]["ms"] > 0 and d["device_warmup"]["warmup_launches_done"] >= 5
     # ... and the figure under rounds 1-4's protocol (W warm-up steps on a device that sat idle) travels next to `value`
-    assert d["from_idle"]["idle_s"] == 2.0 and 0.5 * d["value"] < d["from_idle"]["value"] < 1.1 * d["value"]
+    assert d["from_idle"]["idle_s"] == 2.0 and 0.4 * d["value"] < d["from_idle"]["value"] < 1.3 * d["value"]
 
 
 def test_bench_complete_tick_advances_the_gait_clock(built):
