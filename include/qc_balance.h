@@ -255,7 +255,9 @@ int qc_query_launch(qc_handle* h, size_t n, int kin, int warm, qc_launch_info* o
  * "force_general" / "force_dense" (run the more general formulation on weights that would allow the
  * specialised one; same minimiser), "clamp_steps" (clamp steps a cold-started robot takes before its first ratio test in
  * the one-fill kernels; 0 = the kernel's rule: five on one or two lanes per robot, one on four),
- * "tol_d" (relative multiplier tolerance), "max_iter" (<= 0: back to qc_params.max_iter), "probe_batch_load"
+ * "tol_d" (relative multiplier tolerance), "polish" (1, default: the first time a robot would be accepted while its
+ * smallest multiplier lies inside the noise band +-tol_d |grad|, that face is released once instead; 0: accept at -tol_d |grad|
+ * straight away, round 5's rule - up to tol_d |grad| / (2 w) from the minimiser for very small W), "max_iter" (<= 0: back to qc_params.max_iter), "probe_batch_load"
  * (1: skip the solver iterations - load, assemble, store only; every robot then reports QC_MAX_ITER; 0: back to the
  * handle's own cap).  "force_general" / "force_dense" / "max_iter" / "probe_batch_load" restore what qc_create was given,
  * whatever the order of the calls.

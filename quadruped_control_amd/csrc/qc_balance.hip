@@ -44,6 +44,9 @@ namespace qc {
 // (MODE 0) restocks 64 robots at a time, a one-fill wave (MODE 1/2) only ever holds its 64/G robots, so its
 // stock is 64/G slots - 9.2 KB instead of 18 KB at G = 2, which is what lets more than two workgroups per
 // SIMD share the CU's 160 KB (the 92-VGPR one-fill kernels are register-good for five).
+// "this robot still has its polish release" (Lane::iterate): bit 9 of the stance word wherever a robot travels (stock, hand-over
+// records); inside a lane it is the sign of the lane's multiplier tolerance `tol_s`
+constexpr uint32_t QC_POLISH_ONE = 1u << 9;
 enum { IN_B = 0, IN_R = 6, IN_FLAGS = 18, IN_IDX = 19, IN_PLANES = 20,
        OUT_F = 0, OUT_STAT = 12, OUT_WORD = 13, OUT_IDX = 14, OUT_PLANES = 15,
        STOCK_PLANES = IN_PLANES + OUT_PLANES };
@@ -69,6 +72,7 @@ struct Lane {
   uint32_t stance;  // bits 0-3: LegState per foot, bit 8: non-finite input
   int foot0;        // first foot of this lane
   int status, iters;
+  double tol_s;  // relative multiplier tolerance of this robot (tol_d x Eqp::kTolScale), signed: + while it still has its polish release, - after
   bool have_f;
   int nclamp = 1;        // RACE: recalculations that clamp instead of stepping
   bool drop_all = false;  // RACE: drop every negative multiplier after a full step
@@ -80,13 +84,21 @@ struct Lane {
 
   // multiplier test on the current face: true if all active faces have
   // lambda >= -tol; otherwise wcode = 3*foot+axis of the most negative one.
+  // (`worst`: the smallest multiplier, face code in its low bits; `thr` = the bar below which a multiplier is released:
+  // -tol |g|, or +tol |g| while the robot has its polish release - see iterate)
   template <class PT>
-  QC_DEV bool multipliers_ok(const PT& P, const double (&g)[3 * FPL], int& wcode, bool (&neg)[3 * FPL], uint32_t& negbits) const {
+  QC_DEV bool multipliers_ok(const PT& P, const double (&g)[3 * FPL], double gscale, double& worst, double& thr, bool (&neg)[3 * FPL], uint32_t& negbits) const {
     negbits = 0u;
-    double gs = 1.0;
+    // the tolerance is relative to the scale of the multipliers' rounding noise: what the 6x6 forms' solve hands over
+    // (eqp_diagw: group-uniform, ready before the gradient is), max(1, |g|_inf) over the group's feet for the dense forms
+    double gs = gscale;
+    if constexpr (!Eqp::kHasScale) {
+      gs = 1.0;
 #pragma unroll
-    for (int k = 0; k < 3 * FPL; k++) gs = max_abs_nn(gs, g[k]);
-    gs = group_max<G, S>(gs);
+      for (int k = 0; k < 3 * FPL; k++) gs = max_abs_nn(gs, g[k]);
+      gs = group_max<G, S>(gs);
+    }
+    thr = tol_s * gs;
     double cand[3 * FPL];
 #pragma unroll
     for (int i = 0; i < FPL; i++) {
@@ -98,7 +110,6 @@ struct Lane {
       cand[3 * i + 1] = tag(C.sy[i] != 0 ? ly : QC_BIG, c0 + 1);
       cand[3 * i + 2] = tag(C.sz[i] != 0 ? lz : QC_BIG, c0 + 2);
       if constexpr (RACE) {  // per-axis "this multiplier is negative" for the drop-all strategy (compares; the masks live in SGPRs)
-        const double thr = -P.tol_d * gs;
         neg[3 * i + 0] = (C.sx[i] != 0) & (lx < thr);
         neg[3 * i + 1] = (C.sy[i] != 0) & (ly < thr);
         neg[3 * i + 2] = (C.sz[i] != 0) & (lz < thr);
@@ -117,10 +128,8 @@ struct Lane {
     for (int w = 3 * FPL; w > 1; w = (w + 1) / 2)
 #pragma unroll
       for (int k = 0; k < w / 2; k++) cand[k] = min_nn(cand[k], cand[k + (w + 1) / 2]);
-    const double worst = group_min<G, S>(cand[0]);
-    const bool ok = !(worst < -P.tol_d * gs);
-    wcode = ok ? -1 : tag_code(worst);
-    return ok;
+    worst = group_min<G, S>(cand[0]);
+    return !(worst < thr);
   }
 
   // one working-set recalculation; returns true when the robot is finished.
@@ -210,16 +219,34 @@ struct Lane {
     }
     // multiplier test, meaningful when f landed on f^
     const bool at_fh = fresh ? !changed : !blocked;
-    int wcode = -1;
     bool neg[3 * FPL];
 #pragma unroll
     for (int k = 0; k < 3 * FPL; k++) neg[k] = false;
     bool opt = true;
     uint32_t negbits = 0u;  // (FPL == 4 && RACE: `neg` as bits of one register)
-    if (!(PHASE == FIRST && empty_set)) opt = multipliers_ok(P, g, wcode, neg, negbits);
+    double worst = QC_BIG, thr = 0.0;
+    if (!(PHASE == FIRST && empty_set)) opt = multipliers_ok(P, g, eqp.gscale, worst, thr, neg, negbits);
     if constexpr (RACE && FPL == 4) asm volatile("" : "+v"(negbits));
-    if (!at_fh) wcode = -1;
-    const bool dall = RACE & drop_all & at_fh;  // this lane's strategy drops every negative multiplier at once
+    // POLISH.  The bar -tol |g| sits just above the multipliers' rounding noise, and along a weakly active face the objective
+    // curves only with 2w: a multiplier accepted anywhere in (-tol |g|, 0) leaves the force up to tol |g| / (2w) from the
+    // minimiser (w ~ 1e-7: 3e-3 N = 6.9e-5 relative, profiles/r05_fuzz_dig_138.log), and one whose true value is negative but
+    // inside the noise about as far.  So a robot starts with the bar at +tol |g| (`thr` = tol_s x scale, tol_s > 0): a face
+    // whose multiplier lies inside the band (-tol |g|, +tol |g|) counts as not optimal and is released like a negative one, and
+    // the walk goes on as the primal active-set method it is (the objective never increases) - either the larger subproblem's
+    // minimiser is feasible, which is the better point, or the released face blocks at a zero-length step and comes back.
+    // The first release that was NOT of a clearly negative multiplier (|worst| <= tol |g|) flips the robot's tolerance for good:
+    // from then on the rule is round 5's, so a weakly active face is released once and cannot cycle.  Clearly negative
+    // multipliers are dropped as ever and leave the polish release in place.  Per recalculation: one compare and one select
+    // (a budget counter in a register of its own cost the chain-bound kernels 2 %, the flag inside `status` 2.7 %, an EXEC
+    // branch around the test 2-4.5 %: profiles/r06_polish_ab.log).
+    const int wcode = (at_fh & !opt) ? tag_code(worst) : -1;
+    {
+      const bool polish = at_fh & !opt & (__builtin_fabs(worst) <= __builtin_fabs(thr));  // (false once tol_s < 0: then !opt means worst < -tol |g|)
+      const unsigned long long tb = (unsigned long long)__double_as_longlong(tol_s);
+      const uint32_t hi = (uint32_t)(tb >> 32) | (polish ? 0x80000000u : 0u);  // (select between constants: written as a select between the two words it became an EXEC branch)
+      tol_s = __longlong_as_double((long long)(((unsigned long long)hi << 32) | (uint32_t)tb));
+    }
+    const bool dall = RACE & drop_all & at_fh;  // this lane's strategy drops every multiplier below the bar at once
     const bool take_clamp = fresh & changed;
 #pragma unroll
     for (int i = 0; i < FPL; i++) {
@@ -245,8 +272,9 @@ struct Lane {
   }
 
   // take the robot staged in `slot` of the wave's input stock into this lane's group
+  // (`tol` = DevParams::tol_d)
   template <int SP>
-  QC_DEV void load_from_stock(const double* __restrict__ sin, int slot, int member) {
+  QC_DEV void load_from_stock(const double* __restrict__ sin, int slot, int member, double tol) {
     foot0 = member * FPL;
 #pragma unroll
     for (int k = 0; k < 6; k++) {
@@ -260,7 +288,8 @@ struct Lane {
 #pragma unroll
       for (int k = 0; k < 3; k++) Wr.r[i][k] = sin[(IN_R + 3 * (foot0 + i) + k) * SP + slot];
     const unsigned long long fl = (unsigned long long)__double_as_longlong(sin[IN_FLAGS * SP + slot]);
-    stance = (uint32_t)fl;
+    stance = (uint32_t)fl & ~QC_POLISH_ONE;
+    tol_s = Eqp::kTolScale * (((uint32_t)fl & QC_POLISH_ONE) ? tol : -tol);
     const uint32_t wv = (uint32_t)(fl >> 32);
     idx = __double_as_longlong(sin[IN_IDX * SP + slot]);
     const bool use_warm = (wv & 0x80000000u) != 0;
@@ -280,7 +309,7 @@ struct Lane {
   }
 
   // take a freshly assembled robot straight from registers (one lane per robot, no stock in between)
-  QC_DEV void load_direct(const Wrench<FPL>& W, uint32_t st, uint32_t wv, long robot, int member) {
+  QC_DEV void load_direct(const Wrench<FPL>& W, uint32_t st, uint32_t wv, long robot, int member, double tol) {
     static_assert(G == 1, "one lane assembles and solves the whole robot");
     foot0 = member * FPL;
 #pragma unroll
@@ -292,7 +321,8 @@ struct Lane {
     for (int i = 0; i < FPL; i++)
 #pragma unroll
       for (int k = 0; k < 3; k++) Wr.r[i][k] = W.r[i][k];
-    stance = st;
+    stance = st & ~QC_POLISH_ONE;
+    tol_s = Eqp::kTolScale * ((st & QC_POLISH_ONE) ? tol : -tol);
     idx = robot;
     const bool use_warm = (wv & 0x80000000u) != 0;
 #pragma unroll
@@ -309,6 +339,8 @@ struct Lane {
     iters = 0;
     have_f = false;
   }
+  // bit 9 of the stance word a RUNNING robot travels with (hand-over records)
+  QC_DEV uint32_t polish_bit() const { return tol_s > 0.0 ? QC_POLISH_ONE : 0u; }
   // the working-set word of this lane's feet (bit 31 = valid is added by the caller)
   QC_DEV uint32_t word_bits() const {
     uint32_t word = 0;
@@ -439,7 +471,7 @@ QC_DEV uint32_t assemble_from_state(CParams& P, const BatchIn& in, long robot, i
 #pragma unroll
     for (int i = 0; i < FPL; i++) W.r[i][0] = W.r[i][1] = W.r[i][2] = 0.0;
   }
-  return stance;
+  return stance | (P.polish != 0 ? QC_POLISH_ONE : 0u);  // "still has its polish release" travels in the stance word
 }
 
 template <bool KIN, int FPL, bool STR>
@@ -807,7 +839,7 @@ QC_DEV void repack_write(const LaneX& L, double* __restrict__ rec, int slot, int
 #pragma unroll
     for (int k = 0; k < 6; k++) rec[k] = L.Wr.b[k];
     rec[6] = __longlong_as_double(L.idx);
-    rec[7] = __longlong_as_double((long long)(((unsigned long long)(uint32_t)((L.iters << 8) | slot) << 32) | L.stance));
+    rec[7] = __longlong_as_double((long long)(((unsigned long long)(uint32_t)((L.iters << 8) | slot) << 32) | L.stance | L.polish_bit()));
   }
 #pragma unroll
   for (int i = 0; i < FPL; i++) {
@@ -837,10 +869,14 @@ QC_DEV int repack_read(const DevParams* __restrict__ Pg, Lane4X& L4, Eqp4X& eqp4
   L4.C.sx[0] = dec2(fw); L4.C.sy[0] = dec2(fw >> 2); L4.C.sz[0] = dec2(fw >> 4);
   L4.idx = __double_as_longlong(rec[6]);
   const unsigned long long fl = (unsigned long long)__double_as_longlong(rec[7]);
-  L4.stance = (uint32_t)fl;
+  L4.stance = (uint32_t)fl & ~QC_POLISH_ONE;
   L4.iters = (int)(fl >> 40);
   L4.foot0 = j4;
   L4.status = QC_MAX_ITER;
+  {
+    const double tol = Eqp4X::kTolScale * QC_PARAMS_HERE(Pg)->tol_d;
+    L4.tol_s = ((uint32_t)fl & QC_POLISH_ONE) ? tol : -tol;
+  }
   L4.have_f = true;
   eqp4.setup(*QC_PARAMS_HERE(Pg), L4.Wr, j4);
   return (int)((fl >> 32) & 0xFFu);
@@ -1062,7 +1098,18 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
 #pragma unroll
           for (int k = 0; k < 9; k++) sin[k * SP + lane] = S.R[k];
         }
-        L.load_direct(W, st, wv, robot, 0);
+        L.load_direct(W, st, wv, robot, 0, P.tol_d);
+      } else if constexpr (TWIN) {
+        // The wave-uniform loops below run every lane through the recalculation body, the lanes beyond a ragged last fill
+        // included: they carry a defined robot - no wrench, no stance foot (every foot eliminated, nothing to iterate on) -
+        // instead of whatever the registers held.  They never store.  (Shadowing robot 0 of the wave, as the strided kernels'
+        // spare groups do, costs this 512-register kernel 12 B of scratch.)
+        Wrench<4> W;
+#pragma unroll
+        for (int k = 0; k < 6; k++) W.b[k] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) W.r[i][0] = W.r[i][1] = W.r[i][2] = 0.0;
+        L.load_direct(W, 0u, 0u, -1, 0, 0.0);
       }
     } else {
       stock_n = restock<G, KIN, STR, SP>(Pg, in, warm, cursor, end, lane, member, sin);
@@ -1090,7 +1137,10 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
         L.nclamp = sid == 3 ? 3 : (sid == 2 ? 2 : 1);
         L.drop_all = sid == 1 || sid == 2;
       }
-      L.template load_from_stock<SP>(sin, busy ? slot : 0, member);
+      double tol0;  // (RESIDENT: from the register copy - another scalar load here is a memory round trip a lone wave waits out)
+      if constexpr (RESIDENT) tol0 = uc.tol_d;
+      else tol0 = QC_PARAMS_HERE(Pg)->tol_d;
+      L.template load_from_stock<SP>(sin, busy ? slot : 0, member, tol0);
       eqp.setup(*QC_PARAMS_HERE(Pg), L.Wr, L.foot0);
       busy = busy && !probe;
       unsigned solved_mask = 0;  // RACE: strategies of this lane's robot that have reached the KKT point
@@ -1167,8 +1217,8 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
       QC_CLK_END(8);
       return;
     }
-    if (busy) {
-      if constexpr (!DIRECT) L.template load_from_stock<SP>(sin, grp, member);
+    if (busy || TWIN) {  // (TWIN: the shadow lanes of a ragged fill get their Hessian column too)
+      if constexpr (!DIRECT) L.template load_from_stock<SP>(sin, grp, member, QC_PARAMS_HERE(Pg)->tol_d);
       eqp.setup(*QC_PARAMS_HERE(Pg), L.Wr, L.foot0);
     }
     const bool mine = busy;
@@ -1256,6 +1306,7 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
         const uint32_t wbits = (uint32_t)take_i((int)L.word_bits());
         const uint32_t stance_o = (uint32_t)take_i((int)L.stance);
         const int iters_o = take_i(L.iters);
+        const double tol_o = take_d(L.tol_s);
         const int idx_lo = take_i((int)(unsigned)(unsigned long long)L.idx), idx_hi = take_i((int)(unsigned)((unsigned long long)L.idx >> 32));
         // (one value at a time, selected in place: two dozen temporaries next to the 78-entry factor's registers would spill)
 #pragma unroll
@@ -1270,6 +1321,7 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
           L.iters = iters_o;
           L.idx = (long)(((unsigned long long)(unsigned)idx_hi << 32) | (unsigned)idx_lo);
           L.status = QC_MAX_ITER;
+          L.tol_s = tol_o;
           L.have_f = true;
           L.drop_all = true;
           L.foot0 = 0;
@@ -1351,7 +1403,7 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
       const int take = n_free < have ? n_free : have;
       const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(~busy_mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)~busy_mask, 0)) / G;
       if (!busy && rank < take) {
-        L.template load_from_stock<SP>(sin, stock_next + rank, member);
+        L.template load_from_stock<SP>(sin, stock_next + rank, member, QC_PARAMS_HERE(Pg)->tol_d);
         CParams& P = *QC_PARAMS_HERE(Pg);
         eqp.setup(P, L.Wr, L.foot0);
         busy = true;
@@ -1460,6 +1512,7 @@ __global__ __launch_bounds__(128, 2) void balance_pair_kernel(const DevParams* _
     L.idx = -1;
     L.foot0 = 0;
     L.stance = 0;
+    L.tol_s = 0.0;
     bool busy = false;
     if (mine) {
       const uint32_t sw = in.stance ? *reinterpret_cast<const uint32_t*>(in.stance + 4 * robot) : 0u;
@@ -1475,7 +1528,7 @@ __global__ __launch_bounds__(128, 2) void balance_pair_kernel(const DevParams* _
       const uint32_t st = assemble_from_state<KIN, 4, false>(P, in, robot, 0, S, fp, sw, X, W);
 #pragma unroll
       for (int k = 0; k < 9; k++) lds.Rrows[9 * slot + k] = S.R[k];
-      L.load_direct(W, st, wv, robot, 0);
+      L.load_direct(W, st, wv, robot, 0, P.tol_d);
       eqp.setup(P, L.Wr, 0);
       busy = P.max_iter != 0;  // (0: the batch-load probe - load -> assemble -> store only)
     }
@@ -1502,7 +1555,7 @@ __global__ __launch_bounds__(128, 2) void balance_pair_kernel(const DevParams* _
       double* rec = list + (first + rank) * PAIR_REC;
 #pragma unroll
       for (int k = 0; k < 6; k++) rec[k] = L.Wr.b[k];
-      const unsigned long long fl = (unsigned long long)slot | ((unsigned long long)(L.stance & 0x1FFu) << 8) |
+      const unsigned long long fl = (unsigned long long)slot | ((unsigned long long)((L.stance | L.polish_bit()) & 0x3FFu) << 8) |
                                     ((unsigned long long)(L.word_bits() & 0xFFFFFFu) << 24) | ((unsigned long long)(uint32_t)L.iters << 48);
       rec[6] = __longlong_as_double((long long)fl);
 #pragma unroll
@@ -1553,6 +1606,10 @@ __global__ __launch_bounds__(128, 2) void balance_pair_kernel(const DevParams* _
     L4.iters = (int)(fl >> 48);
     L4.foot0 = j4;
     L4.status = QC_MAX_ITER;
+    {
+      const double tol = Eqp4::kTolScale * QC_PARAMS_HERE(Pg)->tol_d;
+      L4.tol_s = ((fl >> 8) & QC_POLISH_ONE) ? tol : -tol;
+    }
     L4.have_f = true;
     eqp4.setup(*QC_PARAMS_HERE(Pg), L4.Wr, j4);
   };
@@ -2172,6 +2229,7 @@ int qc_create_abi(const qc_params* p, int device, qc_handle** out, int abi_versi
   h->cfg_max_iter = d.max_iter;
   d.clamp_steps = 0;  // 0: per kernel (clamp_steps_for)
   d.tail_race = 1;
+  d.polish = 1;  // the polish at acceptance (Lane::iterate)
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete h; return fail(QC_ERR_HIP, "qc_create: hipGetDeviceProperties failed"); }
   h->cus = prop.multiProcessorCount;
@@ -2235,6 +2293,7 @@ int qc_set_tuning(qc_handle* h, const char* key, double value) {
     h->dp.max_iter = value > 0 ? (int)value : h->cfg_max_iter; params = true;
   }
   else if (k == "clamp_steps") { h->dp.clamp_steps = value >= 1 ? (int)value : 0; params = true; }
+  else if (k == "polish") { h->dp.polish = value != 0 ? 1 : 0; params = true; }  // 0: round 5's acceptance rule
   else if (k == "probe_batch_load") {
     // measurement probe: load -> assemble -> store only (every robot reports QC_MAX_ITER); 0 restores the handle's own cap
     h->probing = value != 0;

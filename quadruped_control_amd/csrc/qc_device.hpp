@@ -74,7 +74,7 @@ struct DevParams {
   int max_iter;
   int clamp_steps;     // clamp steps a fresh robot takes before its first ratio test (one-fill kernels)
   int tail_race;       // the 4-lane tail races two drop rules on its last <= 8 robots
-  int pad;
+  int polish;          // 1: a robot whose smallest multiplier is inside the noise band at its first acceptance releases that face once
 };
 
 // Device code reads the constants through the CONSTANT address space (scalar
@@ -1016,7 +1016,7 @@ QC_DEV FootCoef foot_coef(const PT& P, const FootW& fw, int sx, int sy, int sz, 
 // `lane_w`: the lane's foot weights (general form with lane groups; ignored otherwise).
 template <bool UNIFORM, int G, bool S, class PT>
 QC_DEV bool eqp_diagw(const PT& P, const FootW (&lane_w)[4 / G], const Wrench<4 / G>& Wr, const Cube<4 / G>& C, uint32_t stance, int foot0,
-                      double (&f)[12 / G], double (&g)[12 / G]) {
+                      double (&f)[12 / G], double (&g)[12 / G], double& vmax) {
   constexpr int FPL = 4 / G;
   // weights of foot i of this lane: compile-time table entries when the lane owns all feet, its registers otherwise
   auto weights = [&](int i) -> FootW {
@@ -1131,6 +1131,15 @@ QC_DEV bool eqp_diagw(const PT& P, const FootW (&lane_w)[4 / G], const Wrench<4 
     v[k] = t;
   }
 #undef MI
+  // Scale of the multipliers' rounding noise, for the caller's acceptance test: g = 2 (A^T v + W f) and every entry of A^T v is
+  // v_a + v_b r - v_c r', so the noise in g is eps |v| (1 + 2 |r|) - a multiple of |v|_inf, which every lane of the group holds
+  // bit-identically (the 6x6 solve is replicated).  Until round 5 the scale was max(1, |g|_inf) over the group's feet: up to
+  // twelve maxima plus a cross-lane reduction at the END of the recalculation's chain; this is six maxima off it.
+  // max(0.25, |v|_inf): the caller's tolerance carries the factor 4 (kTolScale), i.e. the scale is max(1, 4 |v|_inf) >= |g|_inf
+  // for lever arms up to half a metre and within a small factor of it beyond.
+  vmax = max_abs_nn(0.25, v[0]);
+#pragma unroll
+  for (int k = 1; k < 6; k++) vmax = max_abs_nn(vmax, v[k]);
   QC_CLK_PIN(v);
   QC_CLK(5, 6);
   // pass 2: forces and gradient of this lane's feet
@@ -1170,6 +1179,9 @@ struct EqpDiagW {
   static constexpr bool kUniform = UNIFORM;
   static constexpr bool kRepackTail = GROUP <= 2;  // one-fill waves finish their stragglers 4 lanes per robot
   static constexpr bool kNegB = true;  // the lane keeps -b (what the right-hand side adds), not b: no negation per recalculation
+  static constexpr bool kHasScale = true;  // solve() leaves the group-uniform scale of the multipliers' noise in `gscale`
+  static constexpr double kTolScale = 4.0; // ... as max(0.25, |v|_inf): the lane's tolerance carries the 4 (eqp_diagw)
+  double gscale;
   FootW lane_w[4 / GROUP];  // general form with lane groups: the weights of this lane's feet (dead otherwise)
   QC_DEV explicit EqpDiagW(double*) {}
   // called when the lane takes a robot; `foot0` = first foot of the lane
@@ -1182,7 +1194,7 @@ struct EqpDiagW {
   template <class PT>
   QC_DEV bool solve(const PT& P, const Wrench<4 / GROUP>& Wr, const Cube<4 / GROUP>& C, uint32_t stance, int foot0, double (&f)[12 / GROUP],
                     double (&g)[12 / GROUP]) {
-    return eqp_diagw<UNIFORM, GROUP, STRIDED>(P, lane_w, Wr, C, stance, foot0, f, g);
+    return eqp_diagw<UNIFORM, GROUP, STRIDED>(P, lane_w, Wr, C, stance, foot0, f, g, gscale);
   }
 };
 
@@ -1205,6 +1217,9 @@ struct EqpDense {
   static constexpr bool kStrided = false;
   static constexpr bool kRepackTail = false;
   static constexpr bool kNegB = false;
+  static constexpr bool kHasScale = false;  // the acceptance test scales with max(1, |g|_inf) of the lane group
+  static constexpr double kTolScale = 1.0;
+  double gscale;  // (unused)
   double* Qs;    // LDS base of this lane: element k at Qs[k * 64]
   double c[12];  // c = -2 A^T S b (BC.cpp:153)
 
@@ -1392,6 +1407,9 @@ struct EqpDense4 {
   static constexpr bool kUniform = false;
   static constexpr bool kRepackTail = false;
   static constexpr bool kNegB = false;
+  static constexpr bool kHasScale = false;  // the acceptance test scales with max(1, |g|_inf) of the lane group
+  static constexpr double kTolScale = 1.0;
+  double gscale;  // (unused)
   static constexpr int XS = 17;           // tile stride in doubles (16 robots + 1)
   static constexpr int X_DOUBLES = 156 * XS;
   double* X;        // this robot's column of the wave's exchange tile
