@@ -3,8 +3,11 @@ the driver runs them: random constructor arguments (mu 0.05-2, w 1e-7-1e-2, fzmi
 with cold and warm-started ticks, and wild robot states (rotations up to pi, arbitrary contact patterns, large
 velocities) - GPU against the C oracle.  Fixed seeds: the trials are a deterministic sequence, the budget only decides
 how far down the sequence a run gets (the long versions are `python tests/stress_fuzz.py [trials] [robots]`).
-Bars: no status mismatch; forces within north_star's 1e-4 relative (the campaigns' known worst is 2.9e-6, reached by
-parameter sets with w <= 2e-7 where the 6x6 form's conditioning shows - DESIGN.md section 5)."""
+Bars: no status mismatch; forces within 2e-5 relative - north_star's bar is 1e-4; this deterministic sequence's worst is 2.9e-6,
+and three 20 000-trial campaigns on other seeds reach 1.4e-5 ... 2.4e-5 (profiles/r06_fuzz_campaigns.log), all of it at
+w <= 2e-7 with few free variables, where the 6x6 dual form's conditioning eps (S/w) |b| shows - identical working sets, GPU
+stationarity 1e-8.  Round 5's 6.9e-5 (seed 555, trial 138) was the acceptance threshold's reach tol |g| / (2w) and is gone with
+the polish at acceptance (2.9e-8 on every form: profiles/r06_polish_ab.log)."""
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -14,7 +17,7 @@ def test_parameter_fuzz_30s(built):
     from tests import stress_fuzz
 
     worst, mismatches, done = stress_fuzz.run(trials=900, n=2048, budget_s=30.0)
-    assert done >= 6 and mismatches == 0 and worst < 1e-4, (worst, mismatches, done)
+    assert done >= 6 and mismatches == 0 and worst < 2e-5, (worst, mismatches, done)
 
 
 def test_state_fuzz_30s(built):
