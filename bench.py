@@ -448,6 +448,23 @@ def cpu_baseline_tick(P, batch, budget_s=2.5):
             "single_thread_value": one, "cpu_model": cpu_model(), "threads": threads, "compiler": oracle_build_flags()}
 
 
+def probe_pmc(sha):
+    """The committed rocprofv3 passes of the batch-load probe on THESE kernel sources (profiles/rNN_batchload.json, written by
+    tools/profile_probe.sh + tools/summarize_probe.py: one --kernel-trace --stats pass, separate --pmc FETCH_SIZE / WRITE_SIZE
+    passes, FETCH_SIZE doubled per MI355X_MICROARCH.md), or None."""
+    import glob
+
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_batchload.json"))):
+        try:
+            d = json.load(open(f))
+            if d.get("kernel_src_sha16") == sha and "traffic" in d:
+                best = (d, os.path.relpath(f, ROOT))
+        except Exception:
+            pass
+    return best
+
+
 def batch_load_probe(q, P, device, nb=2097152, steps=10):
     """north_star: "achieved HBM GB/s on the batch load".  Same kernel with the solver iterations skipped
     (qc_set_tuning "probe_batch_load": load -> PD law / rotation log / Newton-Euler rhs -> output transform -> store;
@@ -464,9 +481,19 @@ def batch_load_probe(q, P, device, nb=2097152, steps=10):
            "status": torch.empty((nb,), dtype=torch.int32, device=f"cuda:{device}")}
     _, evs = time_launches([probe.plan_batch(batch, out=out)[0]], steps, 2, warm_ms=SWEEP_WARM_MS)
     gbs = BYTES_PER_ROBOT_COLD * nb * steps / evs / 1e9
-    return {"robots": nb, "bytes": BYTES_PER_ROBOT_COLD * nb, "us": evs / steps * 1e6, "achieved": gbs, "unit": "GB/s",
-            "peak": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS,
-            "what": "load -> assemble (PD law, rotation log, Newton-Euler rhs) -> output transform -> store, no QP iterations"}
+    out = {"robots": nb, "bytes": BYTES_PER_ROBOT_COLD * nb, "us": evs / steps * 1e6, "achieved": gbs, "unit": "GB/s",
+           "peak": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS, "kernel": probe.kernel_name, "kernel_mode": probe.query_launch(nb)["mode"],
+           "traffic": None}
+    pm = probe_pmc(kernel_src_sha16())
+    if pm is not None:  # counters cannot be read from inside the benchmarked process: the hash-matched committed passes
+        d, src = pm
+        out["traffic"] = d["traffic"]["hbm_bytes_per_launch"]
+        out["traffic_ratio_to_algorithmic"] = d["traffic"]["hbm_bytes_per_launch"] / (BYTES_PER_ROBOT_COLD * nb)
+        out["avg_kernel_us_rocprof"] = d["kernel"]["avg_ns"] * 1e-3
+        out["achieved_rocprof"] = BYTES_PER_ROBOT_COLD * nb / d["kernel"]["avg_ns"]  # GB/s, algorithmic bytes / rocprof's kernel average
+        out["traffic_source"] = src + " (rocprofv3 --kernel-trace --stats + separate --pmc FETCH_SIZE / WRITE_SIZE passes of this probe on these kernel sources)"
+    out["what"] = "load -> assemble (PD law, rotation log, Newton-Euler rhs) -> output transform -> store, no QP iterations"
+    return out
 
 
 def host_boundary(ctl, q):
@@ -596,6 +623,8 @@ def main():
     ap.add_argument("--probe-batch-load", action="store_true",
                     help="time the load -> assemble -> store phase alone (no solver iterations) on 2,097,152 robots "
                          "(done by default together with the sweep)")
+    ap.add_argument("--probe-only", action="store_true",
+                    help="profiling (tools/profile_probe.sh): run ONLY the batch-load probe (--steps launches of it) and print its entry with the kernel-source hash")
     ap.add_argument("--tick", choices=["fused", "full", "full-frozen"], default=None,
                     help="development / profiling: time the SURVEY 8(f) tick built around the QP instead of the QP alone - fused = joint_q -> "
                          "FK -> control() -> J^T -> joint_tau; full = + gait clock (dt = 1/300 s per launch), contact rule, foothold planner on every "
@@ -665,6 +694,12 @@ def main():
     torch.cuda.set_device(device)
 
     P = q.cheetah_params(mu=0.6)
+    if args.probe_only:
+        if world != 1:
+            sys.exit("bench.py: --probe-only is a one-GPU profiling mode")
+        print(json.dumps({"batch_load_probe": batch_load_probe(q, P, device, steps=args.steps), "kernel_src_sha16": kernel_src_sha16(),
+                          "steps": args.steps}), flush=True)
+        return
     ctl = q.BalanceController.from_params(P, device=device)
     tune = {kv.split("=")[0]: float(kv.split("=")[1]) for kv in args.tune}
     ctl.set_tuning(**tune)

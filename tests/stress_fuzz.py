@@ -9,29 +9,42 @@ from oracle import c_oracle as O
 
 
 
+def draw_trial(rng, trial):
+    """Constructor arguments and workload seed of trial number `trial` (the generator advances: call it for every trial in turn)."""
+    P = q.cheetah_params(float(rng.choice([0.05, 0.2, 0.6, 1.0, 1.5])) if trial % 5 else float(rng.uniform(0.05, 2.0)))
+    P["fzmin"] = float(rng.choice([0.0, 1.0, 10.0, 40.0]))
+    P["fzmax"] = P["fzmin"] if trial % 17 == 3 else float(P["fzmin"] + 10.0 ** rng.uniform(0.5, 2.5))
+    P["mass"] = float(rng.uniform(2.0, 50.0))
+    P["Ib"] = np.diag(rng.uniform(0.005, 0.5, 3))
+    P["S"] = np.diag(10.0 ** rng.uniform(-1, 2, 6))
+    P["W"] = np.eye(12) * float(10.0 ** rng.uniform(-7, -2))
+    P["kp_p"] = rng.uniform(10, 500, 3); P["kd_p"] = rng.uniform(1, 100, 3)
+    P["kp_w"] = rng.uniform(50, 8000, 3); P["kd_w"] = rng.uniform(5, 800, 3)
+    P["kff"] = rng.uniform(0.0, 0.5, 6)
+    k = trial % 6
+    if k == 1: P["W"] = np.diag(10.0 ** rng.uniform(-6, -3, 12))
+    if k == 2:
+        A = rng.normal(size=(6, 6)); P["S"] = P["S"] + 0.2 * A @ A.T
+    if k == 3:
+        A = rng.normal(size=(12, 12)); P["W"] = P["W"] + 1e-5 * A @ A.T
+    return P, int(rng.integers(1, 2**31))
+
+
+def trial_at(campaign_seed, trial, n=2048):
+    """(P, first-tick batch) of one trial of the campaign QC_FUZZ_SEED = campaign_seed - for regression tests and tools/fuzz_dig.py."""
+    rng = np.random.default_rng(campaign_seed)
+    for t in range(trial + 1):
+        P, seed = draw_trial(rng, t)
+    return P, (W.config4(n, seed=seed)[0] if trial % 2 else W.config3(n, seed=seed))
+
+
 def run(trials=150, n=2048, budget_s=None, min_trials=6):
     """Returns (worst relative error over solved robots, status mismatches, trials done); stops early once budget_s is spent."""
     rng = np.random.default_rng(int(os.environ.get("QC_FUZZ_SEED", 77)))  # QC_FUZZ_SEED: another campaign (the default is the one pytest runs)
     worst = 0.0; bad = 0; t0 = time.time(); forms = {}
     for trial in range(trials):
         if budget_s is not None and trial >= min_trials and time.time() - t0 > budget_s: trial -= 1; break
-        P = q.cheetah_params(float(rng.choice([0.05, 0.2, 0.6, 1.0, 1.5])) if trial % 5 else float(rng.uniform(0.05, 2.0)))
-        P["fzmin"] = float(rng.choice([0.0, 1.0, 10.0, 40.0]))
-        P["fzmax"] = P["fzmin"] if trial % 17 == 3 else float(P["fzmin"] + 10.0 ** rng.uniform(0.5, 2.5))
-        P["mass"] = float(rng.uniform(2.0, 50.0))
-        P["Ib"] = np.diag(rng.uniform(0.005, 0.5, 3))
-        P["S"] = np.diag(10.0 ** rng.uniform(-1, 2, 6))
-        P["W"] = np.eye(12) * float(10.0 ** rng.uniform(-7, -2))
-        P["kp_p"] = rng.uniform(10, 500, 3); P["kd_p"] = rng.uniform(1, 100, 3)
-        P["kp_w"] = rng.uniform(50, 8000, 3); P["kd_w"] = rng.uniform(5, 800, 3)
-        P["kff"] = rng.uniform(0.0, 0.5, 6)
-        k = trial % 6
-        if k == 1: P["W"] = np.diag(10.0 ** rng.uniform(-6, -3, 12))
-        if k == 2:
-            A = rng.normal(size=(6, 6)); P["S"] = P["S"] + 0.2 * A @ A.T
-        if k == 3:
-            A = rng.normal(size=(12, 12)); P["W"] = P["W"] + 1e-5 * A @ A.T
-        seed = int(rng.integers(1, 2**31))
+        P, seed = draw_trial(rng, trial)
         if trial % 2:
             b0, b1 = W.config4(n, seed=seed)
         else:

@@ -10,24 +10,9 @@ want = set(int(a) for a in sys.argv[1:]) or {48, 95, 96}
 n = int(os.environ.get("FUZZ_N", "2048"))
 rng = np.random.default_rng(int(os.environ.get("QC_FUZZ_SEED", 77)))  # the campaign whose trial is being dug out
 FIELDS = ("Rwb", "Rwb_d", "x", "xdot", "w", "x_d", "xdot_d", "w_d", "feet")
+from tests import stress_fuzz
 for trial in range(max(want) + 1):
-    P = q.cheetah_params(float(rng.choice([0.05, 0.2, 0.6, 1.0, 1.5])) if trial % 5 else float(rng.uniform(0.05, 2.0)))
-    P["fzmin"] = float(rng.choice([0.0, 1.0, 10.0, 40.0]))
-    P["fzmax"] = P["fzmin"] if trial % 17 == 3 else float(P["fzmin"] + 10.0 ** rng.uniform(0.5, 2.5))
-    P["mass"] = float(rng.uniform(2.0, 50.0))
-    P["Ib"] = np.diag(rng.uniform(0.005, 0.5, 3))
-    P["S"] = np.diag(10.0 ** rng.uniform(-1, 2, 6))
-    P["W"] = np.eye(12) * float(10.0 ** rng.uniform(-7, -2))
-    P["kp_p"] = rng.uniform(10, 500, 3); P["kd_p"] = rng.uniform(1, 100, 3)
-    P["kp_w"] = rng.uniform(50, 8000, 3); P["kd_w"] = rng.uniform(5, 800, 3)
-    P["kff"] = rng.uniform(0.0, 0.5, 6)
-    k = trial % 6
-    if k == 1: P["W"] = np.diag(10.0 ** rng.uniform(-6, -3, 12))
-    if k == 2:
-        A = rng.normal(size=(6, 6)); P["S"] = P["S"] + 0.2 * A @ A.T
-    if k == 3:
-        A = rng.normal(size=(12, 12)); P["W"] = P["W"] + 1e-5 * A @ A.T
-    seed = int(rng.integers(1, 2**31))
+    P, seed = stress_fuzz.draw_trial(rng, trial)
     if trial not in want:
         continue
     b0 = W.config4(n, seed=seed)[0] if trial % 2 else W.config3(n, seed=seed)
