@@ -301,11 +301,12 @@ def run_config(ctl, q, cfg, n, start, steps, warmup, dist=None, device=0, fused=
             del snap["phase"]
     if "warm" in protocols:
         res["warm_cache"] = time_launches(launches[:1], steps, warmup, dist, warm_ms=warm_ms)
-    if from_idle_s > 0.0 and "cold" in protocols and dist is None:
+    if from_idle_s > 0.0 and "cold" in protocols:
         # rounds 1-4's protocol, for continuity: exactly W warm-up steps on a device that has been idle (what a timed region that
-        # follows seconds of host-side input generation sees) - reported next to `value`, never as `value`
+        # follows seconds of host-side input generation sees) - reported next to `value`, never as `value`; with ranks, under the
+        # same barrier bracket as `value` (every line carries the figure that compares with earlier rounds)
         time.sleep(from_idle_s)
-        res["cold_from_idle"] = time_launches(launches, steps, warmup, None, warm_all=stateful, warm_ms=0.0)
+        res["cold_from_idle"] = time_launches(launches, steps, warmup, dist, warm_all=stateful, warm_ms=0.0)
     res["solved"] = int((out["status"][:n] == 0).sum().item())
     res["solved_all_sets"] = int((out["status"] == 0).sum().item()) if "cold" in protocols else res["solved"]
     return res
@@ -594,6 +595,44 @@ def rates(r, key, n, steps, bytes_per):
     return {"QPs_per_s": n * steps / wall, "avg_kernel_us": evs / steps * 1e6, "hbm_GBs": bytes_per * n * steps / evs / 1e9}
 
 
+def parse_rccl_log(text, world):
+    """What RCCL said about the communicator it built (NCCL_DEBUG=INFO, subsystems INIT,GRAPH - set by main() for the group formation
+    and its first all-reduce only): ranks, channels, and over WHAT each rank reaches its peers.  RCCL prints one line per channel and
+    peer, "Channel 03/0 : 2[2] -> 3[3] via P2P/IPC" (xGMI / PCIe peer access), "... via SHM/direct/direct" (host memory) or
+    "... via NET/..." - counted here as they come; the first matching lines travel verbatim in `lines`, so the record explains itself
+    even where this parser has never seen the format (it has only ever run on one-GPU boxes)."""
+    import re
+
+    via = {}
+    chans = set()
+    nranks = None
+    graph = {}
+    keep, seen_kinds = [], {}
+    for ln in text.splitlines():
+        body = re.sub(r"^.*NCCL INFO ", "", ln)
+        m = re.search(r"Channel (\d+)(?:/\d+)?\s*:\s*(\d+)\[[^\]]*\]\s*->\s*(\d+)\[[^\]]*\]\s*(?:\[\w+\]\s*)?via\s+(\S+)", ln)
+        if m:
+            chans.add(int(m.group(1)))
+            via[m.group(4)] = via.get(m.group(4), 0) + 1
+        m2 = re.search(r"nranks\s+(\d+)", ln)
+        if m2:
+            nranks = int(m2.group(1))
+        m3 = re.search(r"Pattern (\d+).*nChannels (\d+), bw ([\d.]+)/([\d.]+), type (\S+?),", ln)  # the topology search's result: link type per pattern (XGMI / PIX / ...)
+        if m3:
+            graph["pattern%s" % m3.group(1)] = {"nChannels": int(m3.group(2)), "bw": float(m3.group(3)), "type": m3.group(5)}
+        kind = ("via" if " via " in body else "nranks" if "nranks" in body else "pattern" if body.startswith("Pattern") else "xgmi" if re.search(r"xgmi", body, re.I)
+                else "connected" if "Connected all" in body else "ring" if re.match(r"Ring \d", body) else "tree" if re.match(r"Tree \d", body) else None)
+        cap = {"via": 8, "nranks": 2, "pattern": 4, "xgmi": 6, "connected": 2, "ring": 2, "tree": 2}
+        if kind and seen_kinds.get(kind, 0) < cap[kind]:
+            seen_kinds[kind] = seen_kinds.get(kind, 0) + 1
+            keep.append(body[:170])
+    kinds = sorted(via)
+    transport = ("none (one rank)" if world == 1 else
+                 "P2P (xGMI / peer access)" if kinds and all(k.startswith("P2P") for k in kinds) else
+                 "+".join(kinds) if kinds else "unknown (no channel lines in the log)")
+    return {"nranks": nranks, "channels": len(chans) or None, "via": via, "graph": graph, "transport": transport, "lines": keep}
+
+
 def free_port():
     import socket
 
@@ -636,6 +675,16 @@ def main():
     args = ap.parse_args()
 
     one_dev = os.environ.get("QC_BENCH_ONE_DEVICE") == "1"  # test hook: all ranks on cuda:0, gloo instead of RCCL
+    # the N > 1 line says HOW RCCL moved its bytes.  RCCL fixes its debug level the first time anything in the
+    # library logs - possibly while torch is being imported - so the variables are set HERE, before `import torch`, for every process of
+    # a run that will form a process group (the self-launched ranks inherit them; %p = each rank's own pid).  Subsystems INIT and
+    # GRAPH only: the communicator's construction is logged, a collective in the timed region is not.
+    # (a quiet level in the environment - the GPU boxes export NCCL_DEBUG=VERSION - is raised; a caller already debugging at INFO / TRACE keeps its own setup)
+    if (args.gpus > 1 or os.environ.get("QC_BENCH_FORCE_DIST") == "1") and os.environ.get("NCCL_DEBUG", "").upper() not in ("INFO", "TRACE"):
+        import tempfile
+
+        os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,GRAPH", NCCL_DEBUG_FILE=os.path.join(tempfile.gettempdir(), "qc_bench_rccl_%p.log"),
+                          QC_BENCH_RCCL_LOG="1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # no launcher: start the N ranks ourselves, one per GPU
         import torch
@@ -672,6 +721,10 @@ def main():
         limit = float(os.environ.get("QC_BENCH_TIMEOUT_S", "60"))
         os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
         backend = "gloo" if (one_dev and os.environ.get("QC_BENCH_ONE_DEVICE_BACKEND", "gloo") == "gloo") else "nccl"
+        # (each rank's RCCL writes its own log file - see the top of main(); it is read right after the first all-reduce)
+        rccl_log = None
+        if backend == "nccl" and os.environ.get("QC_BENCH_RCCL_LOG") == "1":
+            rccl_log = os.environ["NCCL_DEBUG_FILE"].replace("%p", str(os.getpid()))
         try:
             if one_dev:
                 local_rank = 0  # test hook: every rank on cuda:0 (gloo; "nccl" where RCCL accepts two ranks per device)
@@ -684,12 +737,28 @@ def main():
                 torch.cuda.synchronize()
             if int(probe.item()) != world:
                 raise RuntimeError(f"first all-reduce saw {int(probe.item())} of {world} ranks")
+            rccl_info = {"backend": backend}
+            if backend == "nccl":
+                try:
+                    txt = open(rccl_log).read() if rccl_log and os.path.exists(rccl_log) else ""
+                    rccl_info.update(parse_rccl_log(txt, world))
+                    rccl_info["log_bytes"] = len(txt)
+                    if rccl_log and os.path.exists(rccl_log):
+                        os.remove(rccl_log)
+                except Exception as e:  # noqa: BLE001 - diagnostics must not end the run
+                    rccl_info["error"] = f"{type(e).__name__}: {e}"
+                nd = torch.cuda.device_count()
+                rccl_info["visible_devices"] = nd
+                rccl_info["peer_access"] = [[int(i == j or torch.cuda.can_device_access_peer(i, j)) for j in range(nd)] for i in range(nd)] if nd <= 16 else None
+                rccl_info["log_source"] = "NCCL_DEBUG=INFO NCCL_DEBUG_SUBSYS=INIT,GRAPH, this rank's file" if rccl_log else "NCCL_DEBUG was set by the caller: not captured"
         except Exception as e:  # noqa: BLE001 - whatever went wrong, say which rank and where it was waiting
             print(f"bench.py: rank {rank}/{world} (local GPU {local_rank}, backend {backend}, master "
                   f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}): the process group did not form within "
                   f"{limit:.0f} s - {type(e).__name__}: {str(e).splitlines()[0] if str(e) else ''}", file=sys.stderr, flush=True)
             os._exit(3)
         dist = dist_mod
+    else:
+        rccl_info = None
     device = local_rank if dist is not None else 0
     torch.cuda.set_device(device)
 
@@ -722,7 +791,7 @@ def main():
 
     fused = {None: False, "fused": True, "full": "full", "full-frozen": "full-frozen"}[args.tick]
     res = run_config(ctl, q, cfg, n, start, args.steps, args.warmup, dist, device, fused=fused, warm_ms=args.device_warm_ms,
-                     from_idle_s=2.0 if (world == 1 and args.device_warm_ms > 0 and not args.no_cpu_baseline) else 0.0)
+                     from_idle_s=2.0 if args.device_warm_ms > 0 else 0.0)
 
     from quadruped_control_amd.sharding import reduce_counters
 
@@ -730,6 +799,7 @@ def main():
     rdev = f"cuda:{device}" if on_gpu else None
     wall, solved_total, total_robots = reduce_counters(dist, res["cold"][0], res["solved"], n, device=rdev)
     wall_warm, _, _ = reduce_counters(dist, res["warm_cache"][0], 0, 0, device=rdev)
+    wall_idle = reduce_counters(dist, res["cold_from_idle"][0], 0, 0, device=rdev)[0] if "cold_from_idle" in res else None  # (max over ranks, like `wall`)
     from quadruped_control_amd.sharding import reduce_rank_stats
 
     k_min, k_max, allreduce_s = reduce_rank_stats(dist, res["cold"][1] / args.steps * 1e6, device=rdev)
@@ -775,7 +845,7 @@ def main():
                                       "(capped at 8), then until `ms` of wall time have passed - after the host-side input generation the device "
                                       "needs 10-20 ms of work to be back at its running clocks (profiles/r05_tick_protocol_*.log); "
                                       "`--device-warm-ms 0` times the ramp instead"},
-            **({"from_idle": {"value": total_robots * args.steps / res["cold_from_idle"][0], "ms_per_step": res["cold_from_idle"][0] / args.steps * 1e3,
+            **({"from_idle": {"value": total_robots * args.steps / wall_idle, "ms_per_step": wall_idle / args.steps * 1e3,
                               "avg_kernel_us": res["cold_from_idle"][1] / args.steps * 1e6, "idle_s": 2.0,
                               "what": "the same K steps after exactly W warm-up steps on a device that sat idle for 2 s first - how rounds 1-4 "
                                       "measured (their timed regions followed the host-side input generation); `value` is the device at its running clocks"}}
@@ -806,7 +876,7 @@ def main():
                                                    f"{res['gait']['edge_legs_per_robot_tick']:.5f} stance->swing edges per robot per tick")
         if dist is not None:
             line["ranks"] = {"avg_kernel_us_min": k_min, "avg_kernel_us_max": k_max,
-                             "allreduce_us": allreduce_s * 1e6, "backend": dist.get_backend(),
+                             "allreduce_us": allreduce_s * 1e6, "backend": dist.get_backend(), "rccl": rccl_info,
                              "what": "slowest / fastest rank's average kernel time (HIP events); one 8-byte all-reduce of the kind that "
                                      "brackets the timed region (barrier + counter reduction are the only collectives: no data-path exchange)"}
         if world > 1 and scaling == "strong":
@@ -857,6 +927,14 @@ def main():
                                           "this batch (strong scaling), so a 1/2/4/8 curve starts HERE, not at this line's `value`"}
             del r
             torch.cuda.empty_cache()
+            # ... and the kernel every rank runs at N = 8: rank 0's shard of that batch (262,144 robots, cold by rotation)
+            r = run_config(ctl, q, 5, CONFIG5_TOTAL // 8, 0, k, 10, None, device, protocols=("cold",), warm_ms=args.device_warm_ms)
+            other["config5_shard8"] = {"robots": CONFIG5_TOTAL // 8, "solved_fraction": r["solved_all_sets"] / (r["sets"] * (CONFIG5_TOTAL // 8)), "sets": r["sets"], "steps": k,
+                                       "cold_cache": rates(r, "cold", CONFIG5_TOTAL // 8, k, BYTES_PER_ROBOT_COLD),
+                                       "what": "robots [0, 262144) of config 5: what one of eight ranks solves per step (no collective on the data path)"}
+            attach_pmc(other["config5_shard8"], 5, CONFIG5_TOTAL // 8, sha, ctl.kernel_name, kernel_us=other["config5_shard8"]["cold_cache"]["avg_kernel_us"])
+            del r
+            torch.cuda.empty_cache()
             # the dense 12x12 form (a general SPD W is part of the reference's constructor contract, balance_controller.hpp:76-77, 85-88),
             # forced on the reference's diagonal W so that the workloads are the headline's: four lanes per robot with racing
             # strategies at config 2's size, one lane per robot with the Hessian staged in LDS at config 3's
@@ -873,18 +951,20 @@ def main():
                 other[f"dense_config{c}"] = e
                 del r
                 torch.cuda.empty_cache()
-            del dense
             # the ticks built around the QP, under the same cold-cache protocol as the hot path
-            for key, c, nn, fz, what in (
-                    ("config2_fused_tick", 2, CONFIG_N[2], True, "joint_q -> forward kinematics -> control() -> clamp(J^T f) -> joint_tau in one launch"),
+            for key, c, nn, fz, what, tctl in (
+                    ("config2_fused_tick", 2, CONFIG_N[2], True, "joint_q -> forward kinematics -> control() -> clamp(J^T f) -> joint_tau in one launch", ctl),
                     ("config3_full_tick", 3, CONFIG_N[3], "full", "joint states + COM state + gait phases + dt -> complete joint torque command "
                      "(gait clock, FK, contact rule, foothold planner on stance->swing edges, swing trajectories, IK, joint PD, QP, J^T) in one launch; "
-                     "every launch is one controller tick (1/300 s) later"),
-                    ("full_tick_262144", 3, 262144, "full", "the same complete tick on 262,144 robots (two rounds of workgroups)")):
+                     "every launch is one controller tick (1/300 s) later", ctl),
+                    ("full_tick_262144", 3, 262144, "full", "the same complete tick on 262,144 robots (two rounds of workgroups)", ctl),
+                    # the tick with a general W (balance_controller.hpp:76-77) - the dense 12x12 form's joint_q kernels
+                    ("dense_full_tick_65536", 3, CONFIG_N[3], "full", "the complete tick with the dense 12x12 form (qc_set_tuning force_dense = 1: the "
+                     "formulation a non-diagonal W selects), one lane per robot, Hessian planes in LDS", dense)):
                 # one protocol for the sweep entry and for the profiled run of the same workload (tools/profile_r.sh -> `bench.py --tick
                 # full --steps 50 --warmup 20`): >= 20 warm-up launches AND >= SWEEP_WARM_MS of GPU work before the clock starts - the
                 # entry used to start 3 launches (0.5 ms) after seconds of host-side input generation, on a device still ramping up
-                r = run_config(ctl, q, c, nn, 0, k, SWEEP_WARMUP, None, device, fused=fz, warm_ms=args.device_warm_ms)
+                r = run_config(tctl, q, c, nn, 0, k, SWEEP_WARMUP, None, device, fused=fz, warm_ms=args.device_warm_ms)
                 gait = r.get("gait")
                 bp = bytes_per_robot(False, fz, gait["edge_legs_per_robot_tick"] if gait else 0.0)
                 tk = "full" if fz == "full" else "fused"
@@ -894,26 +974,56 @@ def main():
                 e["roofline"] = {"bound": "hbm", "achieved": e["cold_cache"]["hbm_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": e["cold_cache"]["hbm_GBs"] / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": bp * nn,
                                  "avg_kernel_us": e["cold_cache"]["avg_kernel_us"]}
-                attach_pmc(e, c, nn, sha, ctl.kernel_name, tick=tk, kernel_us=e["cold_cache"]["avg_kernel_us"])
+                attach_pmc(e, c, nn, sha, tctl.kernel_name, tick=tk, kernel_us=e["cold_cache"]["avg_kernel_us"])
+                if tctl is dense:
+                    e["kernel"] = dense.kernel_name
                 if gait:
                     e["gait_clock"] = gait
-                    if not args.no_cpu_baseline:
+                    if not args.no_cpu_baseline and tctl is ctl:
                         e["cpu_baseline"] = cpu_baseline_tick(P, r["batch"])
                     del r
                     torch.cuda.empty_cache()
                     # rounds 3-4's protocol next to it, for continuity: the same tick with the gait phase frozen (no gait_dt)
-                    r = run_config(ctl, q, c, nn, 0, k, SWEEP_WARMUP, None, device, fused="full-frozen", protocols=("cold",), warm_ms=args.device_warm_ms)
+                    r = run_config(tctl, q, c, nn, 0, k, SWEEP_WARMUP, None, device, fused="full-frozen", protocols=("cold",), warm_ms=args.device_warm_ms)
                     e["frozen_phase"] = {"bytes_per_robot": BYTES_PER_ROBOT_FULL, "cold_cache": rates(r, "cold", nn, k, BYTES_PER_ROBOT_FULL),
                                          "what": "no gait_dt: the phases never move, so GaitScheduler::update and FootPlanner::singleFoot are outside "
                                                  "the timed region (what rounds 3 and 4 reported as the complete tick)"}
                 other[key] = e
                 del r
                 torch.cuda.empty_cache()
+            del dense
             line["other_configs"] = other
         if world == 1 and not args.no_sweep:
             line["host_boundary"] = host_boundary(ctl, q)
         if world == 1 and (args.probe_batch_load or not args.no_sweep):
             line["batch_load_probe"] = batch_load_probe(q, P, device)
+        # the driver keeps the contract's keys and the last 2 000 characters of this line, so the numbers a reader needs
+        # from the long entries above come once more, compactly, as its LAST key (us = average kernel time by HIP events, cold-cache
+        # protocol; QPs = whole-batch throughput; hbm = fraction of 8 TB/s on algorithmic bytes; x = counter traffic / algorithmic)
+        def _short(e):
+            c = e["cold_cache"]
+            o = {"n": e["robots"], "us": round(c["avg_kernel_us"], 2), "QPs": float("%.4g" % c["QPs_per_s"]), "hbm": round(c["hbm_GBs"] / HBM_PEAK_GBS, 4)}
+            t = e.get("hbm_traffic_bytes_per_launch") or e.get("roofline", {}).get("traffic")
+            if t:
+                o["x"] = round(t / (c["hbm_GBs"] * 1e9 * c["avg_kernel_us"] * 1e-6), 3)
+            if "roofline_valu" in e:
+                o["issue"] = round(e["roofline_valu"]["issue_frac"], 3)
+            return o
+        summary = {"sha": sha, "cfg2": {"n": n, "us": round(kernel_s * 1e6, 2), "QPs": float("%.4g" % line["value"]), "hbm": round(line["roofline"]["frac"], 4)} if cfg == 2 and not args.tick else None}
+        if "from_idle" in line:
+            summary["cfg2_from_idle_QPs"] = float("%.4g" % line["from_idle"]["value"])
+        for key, name in (("config3", "cfg3"), ("config4", "cfg4_warm"), ("config5_shard8", "cfg5_shard8"), ("config5_n1", "cfg5_n1"), ("dense_config2", "dense2"),
+                          ("dense_config3", "dense3"), ("config2_fused_tick", "fused_tick4096"), ("config3_full_tick", "tick65536"), ("full_tick_262144", "tick262144"),
+                          ("dense_full_tick_65536", "dense_tick65536")):
+            if key in line.get("other_configs", {}):
+                summary[name] = _short(line["other_configs"][key])
+        if "batch_load_probe" in line:
+            bp_ = line["batch_load_probe"]
+            summary["batch_load"] = {"n": bp_["robots"], "us": round(bp_["us"], 1), "hbm": round(bp_["frac"], 4),
+                                     **({"x": round(bp_["traffic_ratio_to_algorithmic"], 3), "rocprof_us": round(bp_["avg_kernel_us_rocprof"], 1)} if bp_.get("traffic") else {})}
+        if "cpu_baseline" in line:
+            summary["cpu_QPs"] = float("%.4g" % line["cpu_baseline"]["value"])
+        line["summary"] = summary
         print(json.dumps(line), flush=True)
 
     if dist is not None:

@@ -62,8 +62,18 @@ def test_bench_driver_line_with_the_whole_sweep(built):
     for k in CONTRACT + ("roofline", "cpu_baseline", "other_configs", "scaling_n1", "host_boundary", "batch_load_probe", "device_warmup", "warm_cache"):
         assert k in d, k
     oc = d["other_configs"]
-    for k in ("config3", "config4", "config5_n1", "dense_config2", "dense_config3", "config2_fused_tick", "config3_full_tick", "full_tick_262144"):
+    for k in ("config3", "config4", "config5_n1", "config5_shard8", "dense_config2", "dense_config3", "config2_fused_tick", "config3_full_tick", "full_tick_262144",
+              "dense_full_tick_65536"):
         assert k in oc and oc[k]["solved_fraction"] == 1.0 and oc[k]["cold_cache"]["avg_kernel_us"] > 0, k
+    # the tick with a general W has a number (the dense form's joint_q kernel, its clock running like the 6x6 tick's)
+    dt = oc["dense_full_tick_65536"]
+    assert dt["kernel"] == "dense-12x12" and dt["gait_clock"]["stance_to_swing_edges"] > 0 and dt["gait_clock"]["device_phase_vs_replayed_clock_max_abs"] == 0.0
+    # the line ENDS with the compact summary (the driver stores the contract's keys and the last 2 000 characters)
+    assert list(d)[-1] == "summary" and len(json.dumps(d["summary"])) < 1800
+    sm = d["summary"]
+    for k in ("cfg2", "cfg3", "cfg4_warm", "cfg5_shard8", "cfg5_n1", "dense2", "dense3", "fused_tick4096", "tick65536", "tick262144", "dense_tick65536", "batch_load"):
+        assert sm[k]["us"] > 0 and 0 < sm[k]["hbm"] < 1, k
+    assert sm["cfg5_n1"]["QPs"] == float("%.4g" % d["scaling_n1"]["value"]) and sm["sha"] == d["kernel_src_sha16"]
     # the N = 1 point of the scaling curve is named at the top level
     assert d["scaling_n1"]["robots"] == 2097152 and d["scaling_n1"]["value"] == oc["config5_n1"]["cold_cache"]["QPs_per_s"]
     # item 1: the complete tick's clock runs inside the timed region; the frozen-phase figure and a CPU baseline travel with it
@@ -79,6 +89,8 @@ def test_bench_driver_line_with_the_whole_sweep(built):
     assert oc["dense_config3"]["lanes_per_robot"] == 1 and oc["dense_config3"]["kernel_mode"] == 1 and oc["dense_config3"]["lds_bytes"] == 78 * 64 * 8
     assert oc["dense_config3"]["resident_workgroups"] >= 1024  # one workgroup per SIMD (two per CU before the LDS diet)
     assert d["batch_load_probe"]["frac"] > 0.4  # north_star: >= 40 % of HBM peak on the batch load
+    bl = d["batch_load_probe"]  # ... with rocprofv3's kernel time and counters next to it whenever profiles/ holds passes of these kernel sources
+    assert "traffic" in bl and (bl["traffic"] is None or (0.9 < bl["traffic_ratio_to_algorithmic"] < 1.3 and bl["traffic_source"].startswith("profiles/")))
     assert d["device_warmup"]["ms"] > 0 and d["device_warmup"]["warmup_launches_done"] >= 5
     # ... and the figure under rounds 1-4's protocol (W warm-up steps on a device that sat idle) travels next to `value`
     assert d["from_idle"]["idle_s"] == 2.0 and 0.4 * d["value"] < d["from_idle"]["value"] < 1.3 * d["value"]
@@ -118,6 +130,18 @@ def _check_two_rank_line(d, total):
     assert abs(d["scaling_efficiency"] - d["value"] / (2 * ref["value"])) < 1e-12 and "configs[4]" in d["scaling_note"]
     rk = d["ranks"]
     assert 0 < rk["avg_kernel_us_min"] <= rk["avg_kernel_us_max"] and rk["allreduce_us"] > 0 and rk["backend"] in ("gloo", "nccl")
+    _check_rccl_record(rk)
+    assert d["from_idle"]["value"] > 0  # multi-rank lines carry the figure under rounds 1-4's protocol too
+
+
+def _check_rccl_record(rk):
+    """the N > 1 line says how the collective library moved its bytes."""
+    rc = rk["rccl"]
+    assert rc["backend"] == rk["backend"]
+    if rc["backend"] == "nccl":
+        for k in ("nranks", "channels", "via", "transport", "lines", "visible_devices", "peer_access"):
+            assert k in rc, (k, rc)
+        assert rc["visible_devices"] >= 1 and rc["log_bytes"] > 0, rc  # RCCL did write its INIT / GRAPH lines where we told it to
 
 
 def test_bench_two_ranks_torchrun(built):
@@ -166,7 +190,7 @@ def test_bench_eight_ranks_before_the_eight_gpus(built):
     assert ref["robots"] == total and ref["solved_fraction"] == 1.0 and ref["value"] > 0
     assert abs(d["scaling_efficiency"] - d["value"] / (8 * ref["value"])) < 1e-12
     rk = d["ranks"]
-    assert 0 < rk["avg_kernel_us_min"] <= rk["avg_kernel_us_max"] and rk["backend"] == "gloo"
+    assert 0 < rk["avg_kernel_us_min"] <= rk["avg_kernel_us_max"] and rk["backend"] == "gloo" and rk["rccl"] == {"backend": "gloo"}
     assert d["result_gather"]["bytes_per_rank"] == 16384 * 96 and d["result_gather"]["seconds"] > 0
     assert "cpu_baseline" not in d and "roofline" in d
 
@@ -221,6 +245,8 @@ def test_bench_one_rank_over_rccl(built):
     d = _last_json(r.stdout)
     assert d["n_gpus"] == 1 and d["config"]["global_batch"] == 65536 and d["solved_fraction"] == 1.0
     assert d["result_gather"]["bytes_per_rank"] == 65536 * 96 and d["result_gather"]["seconds"] > 0
+    _check_rccl_record(d["ranks"])
+    assert d["ranks"]["rccl"]["transport"] == "none (one rank)" and d["ranks"]["rccl"]["peer_access"][0][0] == 1
 
 
 def test_bench_two_ranks_rccl(built):
@@ -238,3 +264,5 @@ def test_bench_two_ranks_rccl(built):
     d = _last_json(r.stdout)
     _check_two_rank_line(d, 2097152)
     assert d["result_gather"]["seconds"] > 0
+    rc = d["ranks"]["rccl"]  # two devices: RCCL's own words about the transport
+    assert rc["nranks"] == 2 and rc["channels"] and rc["transport"] != "unknown (no channel lines in the log)", rc
