@@ -139,7 +139,7 @@ def _check_rccl_record(rk):
     rc = rk["rccl"]
     assert rc["backend"] == rk["backend"]
     if rc["backend"] == "nccl":
-        for k in ("nranks", "channels", "via", "transport", "lines", "visible_devices", "peer_access"):
+        for k in ("nranks", "channels", "via", "graph", "transport", "lines", "visible_devices", "peer_access"):
             assert k in rc, (k, rc)
         assert rc["visible_devices"] >= 1 and rc["log_bytes"] > 0, rc  # RCCL did write its INIT / GRAPH lines where we told it to
 

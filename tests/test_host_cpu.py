@@ -143,6 +143,138 @@ void helpers(const mat& m, const vec& v) { copy_to_real_t(m, row_major); copy_to
     assert "#include <quadruped_controller/balance_controller.hpp>" in open(os.path.join(ROOT, "tests", "cpp", "adapter_test.cpp")).read()
 
 
+def test_forwarding_header_takes_the_callers_own_types(built, tmp_path):
+    """the branch every real caller takes.  In a catkin build of the reference, `<quadruped_controller/gait.hpp>` (and
+    through it types.hpp), `<quadruped_controller/math/rigid3d.hpp>` and `<armadillo>` are on the include path, so the forwarding header
+    includes them and the adapter must use THEIR LegState / GaitMap / FootholdMap / ForceMap / make_stance_gait and arma's mat / vec / vec3
+    (QC_USE_REFERENCE_TYPES, QC_HAVE_ARMADILLO) without redefining anything.  Neither the reference's tree nor Armadillo exists on the
+    test boxes, so this test writes its OWN minimal stand-ins - declarations in the shapes of types.hpp:91-119, gait.hpp:21 and
+    math/rigid3d.hpp:54, a dozen lines of arma-like vectors; none of it copied - into a temp dir placed BEHIND include/ on the path and
+    compiles (syntax only) a caller shaped like commander_node.cpp:337-338, 507-512."""
+    import subprocess
+
+    inc = tmp_path / "their_tree"
+    (inc / "quadruped_controller" / "math").mkdir(parents=True)
+    (inc / "armadillo").write_text("""
+#pragma once
+#include <cstddef>
+#include <initializer_list>
+#include <vector>
+#define QC_TEST_STANDIN_ARMADILLO 1
+namespace arma {
+typedef unsigned long long uword;
+class vec {
+public:
+  vec() : n_rows(0), n_elem(0) {}
+  explicit vec(uword n) : n_rows(n), n_elem(n), d_(n, 0.0) {}
+  vec(std::initializer_list<double> l) : n_rows(l.size()), n_elem(l.size()), d_(l) {}
+  double& operator()(uword i) { return d_[i]; }
+  const double& operator()(uword i) const { return d_[i]; }
+  uword size() const { return n_elem; }
+  uword n_rows, n_elem;
+private:
+  std::vector<double> d_;
+};
+class vec3 : public vec {
+public:
+  vec3() : vec(3) {}
+  vec3(std::initializer_list<double> l) : vec(l) {}
+};
+class mat {
+public:
+  mat() : n_rows(0), n_cols(0) {}
+  mat(uword r, uword c) : n_rows(r), n_cols(c), d_(r * c, 0.0) {}
+  double& operator()(uword i, uword j) { return d_[j * n_rows + i]; }
+  const double& operator()(uword i, uword j) const { return d_[j * n_rows + i]; }
+  uword n_rows, n_cols;
+private:
+  std::vector<double> d_;
+};
+typedef mat mat33;
+}  // namespace arma
+""")
+    (inc / "quadruped_controller" / "types.hpp").write_text("""
+#pragma once
+#include <map>
+#include <string>
+#include <utility>
+#include <armadillo>
+#define QC_TEST_STANDIN_TYPES 1
+namespace quadruped_controller {
+using arma::mat;
+using arma::vec;
+using arma::vec3;
+enum LegState { swing = 0, stance = 1 };
+typedef std::map<std::string, std::pair<LegState, double>> GaitMap;
+typedef std::map<std::string, vec3> FootholdMap;
+typedef std::map<std::string, vec3> ForceMap;
+typedef std::map<std::string, vec3> TorqueMap;
+}  // namespace quadruped_controller
+""")
+    (inc / "quadruped_controller" / "gait.hpp").write_text("""
+#pragma once
+#include <quadruped_controller/types.hpp>
+#define QC_TEST_STANDIN_GAIT 1
+namespace quadruped_controller {
+GaitMap make_stance_gait();  // declared only, as in the caller's tree (defined in its gait.cpp)
+}
+""")
+    (inc / "quadruped_controller" / "math" / "rigid3d.hpp").write_text("""
+#pragma once
+#include <quadruped_controller/types.hpp>
+#define QC_TEST_STANDIN_RIGID3D 1
+namespace quadruped_controller { namespace math {
+class Quaternion {
+public:
+  Quaternion() {}
+  explicit Quaternion(const mat&) {}
+  mat matrix() const { return mat(3, 3); }
+};
+} }
+""")
+    src = tmp_path / "commander_shaped.cpp"
+    src.write_text("""
+#include <string>
+#include <type_traits>
+#include <vector>
+#include <quadruped_controller/balance_controller.hpp>
+#if !defined(QC_USE_REFERENCE_TYPES) || !defined(QC_HAVE_ARMADILLO)
+#error "the caller's gait.hpp / armadillo are on the path: the adapter must have selected them"
+#endif
+#if !defined(QC_TEST_STANDIN_TYPES) || !defined(QC_TEST_STANDIN_GAIT) || !defined(QC_TEST_STANDIN_RIGID3D) || !defined(QC_TEST_STANDIN_ARMADILLO)
+#error "the forwarding header did not pull in the caller's own neighbours (balance_controller.hpp:13-14)"
+#endif
+using namespace quadruped_controller;
+static_assert(std::is_same<mat, arma::mat>::value && std::is_same<vec3, arma::vec3>::value, "Armadillo's types at the boundary");
+static_assert(std::is_same<ForceMap, std::map<std::string, arma::vec3>>::value, "the caller's ForceMap");
+static_assert(std::is_same<GaitMap, std::map<std::string, std::pair<LegState, double>>>::value, "the caller's GaitMap and LegState");
+static_assert(std::is_same<decltype(make_stance_gait()), GaitMap>::value, "the caller's make_stance_gait");
+// commander_node.cpp:337-338 (construct once, const) and :507-512 (every tick; the result feeds the stance legs' torque map)
+TorqueMap tick(const mat& Ib, const mat& S, const mat& W, const vec& k6, const vec& k3, const std::vector<std::string>& leg_names,
+               const mat& Rwb, const vec3& x, const FootholdMap& foot_actual_map, const GaitMap& gait_map)
+{
+  const BalanceController balance_controller(0.8, 11.0, 10.0, 160.0, Ib, S, W, k6, k3, k3, k3, k3, leg_names);
+  const math::Quaternion q(Rwb);  // (commander_node.cpp:173, 548 reach math:: through this header)
+  const mat Rwb_d = q.matrix();
+  const ForceMap force_map = balance_controller.control(Rwb, Rwb_d, x, x, x, x, x, x, foot_actual_map, gait_map);
+  const ForceMap standing = balance_controller.control(Rwb, Rwb_d, x, x, x, x, x, x, foot_actual_map);  // default: make_stance_gait()
+  TorqueMap torque_map;
+  for (const auto& kv : force_map) torque_map.emplace(kv.first, kv.second);
+  for (const auto& kv : standing) if (gait_map.at(kv.first).first == LegState::stance) torque_map.emplace(kv.first, kv.second);
+  return torque_map;
+}
+""")
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-I", str(inc), str(src)],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    # ... and the same caller WITHOUT their tree still compiles against the adapter's own types (the other branch, as before)
+    src2 = tmp_path / "standalone.cpp"
+    src2.write_text(src.read_text().split("using namespace quadruped_controller;")[0].split("#if !defined(QC_USE_REFERENCE_TYPES)")[0] +
+                    "#ifdef QC_USE_REFERENCE_TYPES\n#error \"no reference tree on the path\"\n#endif\n")
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src2)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+
+
 def test_gait_rule():
     from quadruped_control_amd import LegState, leg_state_from_phase, make_stance_gait, stance_phase
 
