@@ -249,7 +249,10 @@ int qc_query_launch(qc_handle* h, size_t n, int kin, int warm, qc_launch_info* o
  * -DQC_PERSISTENT_6X6=1: elsewhere a launch with 0 fails with QC_ERR_INVALID), "chunk" (robots per wave, 0 = heuristic;
  * beyond one fill only where persistent kernels exist - QC_ERR_INVALID at launch otherwise),
  * "wave_slots" (resident workgroups assumed, 0 = occupancy query), "refill_t", "rounds_cold", "rounds_warm",
- * "race" (-1 heuristic; 0 or 1: one strategy per robot; 2, 4: at most that many racing in the 4-lane one-fill kernels),
+ * "race" (-1 heuristic; 0 or 1: one strategy per robot; 2, 4: at most that many racing in the 4-lane one-fill kernels.  With the
+ * race on - the default for cold batches - a wave forks its last running robots onto idle lanes with a second drop rule, so a robot's
+ * `iterations` (and, under a small max_iter, QC_SOLVED vs QC_MAX_ITER) depend on which robots share its wave, i.e. on the batch
+ * layout; the forces agree to the KKT tolerance either way.  0 is the deterministic mode: one walk per robot whatever its neighbours),
  * "pair" (-1 heuristic, 0 never, 1 whenever one lane per robot on a 6x6 form: the paired-waves kernel, mode 3), "pair_th"
  * (its hand-over threshold, <= 32), "pair_refill" (free lane groups that trigger a refill, 1 ... 16), "pair_solo" (0: pairs in the last round of workgroups too),
  * "force_general" / "force_dense" (run the more general formulation on weights that would allow the

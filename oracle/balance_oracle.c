@@ -587,7 +587,7 @@ void oracle_leg_ik(const oracle_kinematics* k, int leg, const double* foothold, 
  * (Hestenes): columns of A = J V are rotated pairwise until orthogonal, then sigma_i = |a_i|, u_i = a_i / sigma_i,
  * which keeps tiny singular values accurate (nothing is squared).  pinv = sum over sigma_i > tol of v_i u_i^T / sigma_i.
  * Returns 0 if the sweeps do not converge (never observed; the caller then falls through to J^T as the reference does). */
-static int pinv3_keep(const double* J, int keep, double* Jp) {
+static int pinv3_keep(const double* J, int keep, double* Jp, int* rank_arma) {
   double A[3][3], V[3][3];
   for (int i = 0; i < 3; i++)
     for (int j = 0; j < 3; j++) { A[i][j] = J[3 * i + j]; V[i][j] = (i == j) ? 1.0 : 0.0; }
@@ -640,6 +640,10 @@ static int pinv3_keep(const double* J, int keep, double* Jp) {
   for (int a = 0; a < 2; a++)
     for (int b = a + 1; b < 3; b++)
       if (sig[order[b]] > sig[order[a]]) { const int t = order[a]; order[a] = order[b]; order[b] = t; }
+  if (rank_arma) { /* singular values Armadillo's own tolerance keeps */
+    *rank_arma = 0;
+    for (int j = 0; j < 3; j++) *rank_arma += sig[j] > tol ? 1 : 0;
+  }
   for (int m = 0; m < 3 && m < keep; m++) {
     const int j = order[m];
     if (!(sig[j] > tol)) continue;
@@ -649,7 +653,7 @@ static int pinv3_keep(const double* J, int keep, double* Jp) {
   return 1;
 }
 
-int oracle_pinv3(const double* J, double* Jp) { return pinv3_keep(J, 3, Jp); }
+int oracle_pinv3(const double* J, double* Jp) { return pinv3_keep(J, 3, Jp, 0); }
 
 /* Numerical rank the way this build decides it INSIDE the band where it answers with the pseudo-inverse (see
  * oracle_swing_torque): elimination with complete pivoting, a second pivot below 1e-9 of the first counts as zero and a
@@ -683,7 +687,26 @@ int oracle_cp_rank3(const double* J) {
   return rank;
 }
 
-int oracle_pinv3_band(const double* J, double* Jp) { return pinv3_keep(J, oracle_cp_rank3(J), Jp); }
+int oracle_pinv3_band(const double* J, double* Jp) { return pinv3_keep(J, oracle_cp_rank3(J), Jp, 0); }
+
+/* ADVICE r5.  oracle_swing_torque restates the REFERENCE: in the singular band it answers with arma::pinv's own rule (tolerance
+ * 3 sigma_max epsilon, oracle_pinv3).  The device decides the rank differently (complete pivoting, never a third pivot, a second
+ * one only above 1e-9 of the first: qc_device.hpp pinv3_apply, restated as oracle_cp_rank3) - a deliberate deviation
+ * (INTEGRATION.md): where Armadillo keeps a sigma between ~1e-16 and 1e-9 of sigma_max, 1 / sigma is a 1e9 ... 1e16-sized gain
+ * on rounding noise.  Every swing leg on which the two rules would keep a different number of singular values is COUNTED here,
+ * so that the parity tests and fuzz campaigns can assert that the window stays unvisited instead of having the checker agree
+ * with the device by construction. */
+static long pinv_rule_disagreements = 0;
+long oracle_pinv_rule_disagreements(int reset) {
+  long v;
+#pragma omp atomic capture
+  { v = pinv_rule_disagreements; pinv_rule_disagreements += 0; }
+  if (reset) {
+#pragma omp atomic write
+    pinv_rule_disagreements = 0;
+  }
+  return v;
+}
 
 void oracle_swing_torque(const oracle_kinematics* k, int leg, const double* Rwb, const double* x, const double* pos,
                          const double* vel, const double* q, const double* qdot, double* tau) {
@@ -731,9 +754,16 @@ void oracle_swing_torque(const oracle_kinematics* k, int leg, const double* Rwb,
     if (!singular) {
       for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++) Jinv[3 * i + j] = M[i][3 + j];
-    } else if (!oracle_pinv3_band(J, Jinv)) { /* (the rank by this build's rule, the values by the SVD: see oracle_cp_rank3) */
-      for (int i = 0; i < 3; i++)
-        for (int j = 0; j < 3; j++) Jinv[3 * i + j] = J[3 * j + i]; /* :198 */
+    } else {
+      int rank_arma = -1;
+      const int ok = pinv3_keep(J, 3, Jinv, &rank_arma); /* arma::pinv, :196 - Armadillo's tolerance decides the rank */
+      if (ok && rank_arma != oracle_cp_rank3(J)) {        /* the device's rule would keep another rank: counted, see above */
+#pragma omp atomic update
+        pinv_rule_disagreements += 1;
+      }
+      if (!ok)
+        for (int i = 0; i < 3; i++)
+          for (int j = 0; j < 3; j++) Jinv[3 * i + j] = J[3 * j + i]; /* :198 */
     }
   }
   for (int r = 0; r < 3; r++) qd[r] = Jinv[3 * r] * vb[0] + Jinv[3 * r + 1] * vb[1] + Jinv[3 * r + 2] * vb[2]; /* :496-497 */

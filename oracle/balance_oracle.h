@@ -105,6 +105,9 @@ int oracle_pinv3(const double* J9, double* Jp9);
  * of the first - the device's rule, qc_device.hpp pinv3_apply), values from the SVD truncated to that rank */
 int oracle_cp_rank3(const double* J9);
 int oracle_pinv3_band(const double* J9, double* Jp9);
+/* swing legs so far on which arma::pinv's tolerance (what oracle_swing_torque applies) and the device's rank rule (oracle_cp_rank3)
+ * keep a different number of singular values; reset != 0 clears the count after reading it */
+long oracle_pinv_rule_disagreements(int reset);
 /* Swing-leg torque of one leg as commander_node.cpp:482-504 + joint_controller.cpp:21-39 compute it (unclamped):
  * pos/vel = world-frame reference foot state, q/qdot = measured joint state of the leg. */
 void oracle_swing_torque(const oracle_kinematics* k, int leg, const double* Rwb, const double* x, const double* pos,

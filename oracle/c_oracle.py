@@ -166,14 +166,23 @@ def pinv3(J):
 
 
 def pinv3_band(J):
-    """oracle_pinv3_band: what oracle_swing_torque uses inside the band where this build answers with pinv - the rank by the
-    device's complete-pivoting rule (at most 2), the values from the SVD truncated to it.  Returns (pinv, rank)."""
+    """oracle_pinv3_band: the DEVICE's pseudo-inverse restated - the rank by its complete-pivoting rule (at most 2), the values from
+    the SVD truncated to it.  Not what oracle_swing_torque uses (that is arma::pinv's own rule, pinv3); kept to put numbers on where
+    the two differ (tests/test_oracle_cpu.py).  Returns (pinv, rank)."""
     J = np.ascontiguousarray(J, np.float64).reshape(9); out = np.zeros(9)
     lib().oracle_pinv3_band.restype = C.c_int
     lib().oracle_cp_rank3.restype = C.c_int
     ok = lib().oracle_pinv3_band(_dp(J), _dp(out))
     assert ok
     return out.reshape(3, 3), int(lib().oracle_cp_rank3(_dp(J)))
+
+
+def pinv_rule_disagreements(reset=False):
+    """Swing legs so far on which arma::pinv's own tolerance - what oracle_swing_torque applies, like the reference - and the
+    device's rank rule (complete pivoting, oracle_cp_rank3) would keep a different number of singular values: the
+    parity tests assert that this stays 0 instead of letting the checker take its rank from the device."""
+    lib().oracle_pinv_rule_disagreements.restype = C.c_long
+    return int(lib().oracle_pinv_rule_disagreements(C.c_int(1 if reset else 0)))
 
 
 def swing_torque(leg, Rwb, x, pos, vel, q, qdot, kin=None):

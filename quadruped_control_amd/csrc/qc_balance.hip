@@ -1955,11 +1955,14 @@ static int plan_launch(qc_handle* h, long n, bool kin, bool warm, qc_launch_plan
     G = n <= cap4 ? 4 : 1;
     if (h->group_override) G = h->group_override == 4 ? 4 : 1;
     if (QC_PERSISTENT_6X6 && G == 4 && (h->one_fill_override == 0 || h->chunk_override > 16)) G = 1;
+    // a chunk of 17 ... 64 robots is more than a four-lane wave holds and exactly what a one-lane one-fill wave does (ADVICE r5:
+    // rounds 2-4 served such a request on the one-lane kernel; it must not become an error because the four-lane one would have been picked)
+    if (!h->group_override && G == 4 && h->chunk_override > 16 && h->chunk_override <= 64) G = 1;
   }
   lp->pfn = nullptr;
   lp->p_th = lp->p_refill = 0;
   // A request this build cannot honour is an error, not a silent fall-back to one-fill workgroups: the persistent (mode 0)
-  // kernels of the 6x6 forms exist only in -DQC_PERSISTENT_6X6=1 builds.
+  // kernels - of the 6x6 forms and, since round 5, of the one-lane dense form too - exist only in -DQC_PERSISTENT_6X6=1 builds.
   if (!QC_PERSISTENT_6X6 && (h->one_fill_override == 0 || h->chunk_override > 64 / G))
     return fail(QC_ERR_INVALID, "qc_set_tuning: one_fill = 0 / a chunk beyond one fill asks for a persistent-wave kernel, which this "
                                 "build does not contain (compile with -DQC_PERSISTENT_6X6=1)");

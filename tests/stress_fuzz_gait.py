@@ -83,3 +83,6 @@ def run_campaign(runs=6, n=1024, ticks=500, budget_s=None, min_runs=1):
 
 if __name__ == "__main__":
     run_campaign(int(sys.argv[1]) if len(sys.argv) > 1 else 6, int(sys.argv[2]) if len(sys.argv) > 2 else 1024, int(sys.argv[3]) if len(sys.argv) > 3 else 500)
+    from oracle import c_oracle as _O
+
+    print("swing legs on which arma::pinv's rank rule (oracle) and the device's would differ: %d" % _O.pinv_rule_disagreements())

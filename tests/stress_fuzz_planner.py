@@ -61,3 +61,6 @@ def run_campaign(runs=12, n=2048, ticks=60, budget_s=None, min_runs=2):
 
 if __name__ == "__main__":
     run_campaign(int(sys.argv[1]) if len(sys.argv) > 1 else 12, int(sys.argv[2]) if len(sys.argv) > 2 else 2048, int(sys.argv[3]) if len(sys.argv) > 3 else 60)
+    from oracle import c_oracle as _O
+
+    print("swing legs on which arma::pinv's rank rule (oracle) and the device's would differ: %d" % _O.pinv_rule_disagreements())

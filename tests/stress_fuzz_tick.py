@@ -68,3 +68,6 @@ def run(batches=30, n=4096, budget_s=None, min_batches=3):
 
 if __name__ == "__main__":
     run(int(sys.argv[1]) if len(sys.argv) > 1 else 30, int(sys.argv[2]) if len(sys.argv) > 2 else 4096)
+    from oracle import c_oracle as _O
+
+    print("swing legs on which arma::pinv's rank rule (oracle) and the device's would differ: %d" % _O.pinv_rule_disagreements())

@@ -56,9 +56,14 @@ def test_state_fuzz_30s(built):
 def test_tick_fuzz_20s(built):
     """The widened tick (FK -> QP -> J^T, swing legs IK + J^-1 / pinv + PD) with random kinematic models, wild joint angles
     (stretched and folded legs) and swing references far from the feet."""
+    from oracle import c_oracle
     from tests import stress_fuzz_tick
 
+    c_oracle.pinv_rule_disagreements(reset=True)
     worst_f, worst_tau, flips, mismatches, done, nan_one_side = stress_fuzz_tick.run(batches=120, n=4096, budget_s=20.0)
+    # ADVICE r5: the oracle applies arma::pinv's own rank rule, the device its complete-pivoting one; no swing leg of the campaign
+    # (stretched and folded legs, random kinematic models, references far out of reach) sat where the two differ
+    assert c_oracle.pinv_rule_disagreements(reset=True) == 0
     assert done >= 3 and mismatches == 0 and worst_f < 1e-6 and flips == 0 and worst_tau < 1e-6, (worst_f, worst_tau, flips, mismatches, done)
     # ADVICE r4: a torque that is NaN on one side only compares False against any tolerance - it is its own failure (round 4's
     # finding: the device's IK returned numbers where the reference leg is all-NaN).  26 000 batches since the fix: none.
@@ -68,9 +73,12 @@ def test_tick_fuzz_20s(built):
 def test_planner_fuzz_20s(built):
     """The stateful complete tick over 60 ticks with random gait timing, planner gains, swing height and velocity commands:
     the carried swing state and the torques track the oracle tick by tick."""
+    from oracle import c_oracle
     from tests import stress_fuzz_planner
 
+    c_oracle.pinv_rule_disagreements(reset=True)
     worst_tau, worst_p, state_mismatch_ticks, done = stress_fuzz_planner.run_campaign(runs=40, n=2048, ticks=60, budget_s=20.0)
+    assert c_oracle.pinv_rule_disagreements(reset=True) == 0  # (see test_tick_fuzz_20s)
     assert done >= 2 and state_mismatch_ticks == 0 and worst_tau < 1e-6 and worst_p < 1e-9, (worst_tau, worst_p, state_mismatch_ticks, done)
 
 
@@ -78,9 +86,12 @@ def test_gait_clock_fuzz_20s(built):
     """random gait periods (qc_set_gait) and jittered gait_dt over hundreds of ticks, with a quarter of the
     steps aimed at the duty edge's 1e-12 slack (gait.cpp:125-134), the phase wrap and dt = 0 / whole periods: the clock the device
     carries stays bit-equal to the oracle's GaitScheduler::update, and contact states, swing state and torques follow."""
+    from oracle import c_oracle
     from tests import stress_fuzz_gait
 
+    c_oracle.pinv_rule_disagreements(reset=True)
     worst_tau, mismatch_ticks, edges, aimed_hits, done = stress_fuzz_gait.run_campaign(runs=30, n=1024, ticks=500, budget_s=20.0)
+    assert c_oracle.pinv_rule_disagreements(reset=True) == 0  # (see test_tick_fuzz_20s)
     assert done >= 1 and mismatch_ticks == 0 and worst_tau < 1e-6, (worst_tau, mismatch_ticks, done)
     assert edges > 1000 and aimed_hits > 1000, (edges, aimed_hits)  # the campaign really exercised edges and the slack
 

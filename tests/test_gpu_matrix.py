@@ -240,7 +240,8 @@ def test_dense_twin_race_under_caps_bad_inputs_and_ragged_sizes(q, cap):
     rule; results are stored straight from registers, the lanes that finished before the fork included).  Against the same kernel
     with the race off (race = 0): identical statuses, forces to 1e-8, never more recalculations; a recalculation cap that strikes
     before the fork, at it or in the race, NaN / inf inputs (status 3 on either side of the fork) and batch sizes that leave a
-    ragged or a nearly empty last wave."""
+    ragged or a nearly empty last wave.  (A property test of the race itself - the kernel against the same kernel with race = 0;
+    the dense one-lane kernel's comparison with the ORACLE is test_kernel_instantiation_vs_oracle above, race on.)"""
     from quadruped_control_amd import workloads as W
 
     P = q.cheetah_params(0.6)

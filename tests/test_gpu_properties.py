@@ -590,6 +590,44 @@ def test_fused_tick_on_general_and_dense_forms(q, monkeypatch, force):
     assert np.max(np.abs(o["joint_tau"] - ref["joint_tau"])) < 2e-5
 
 
+@pytest.mark.parametrize("form", ["force_general", "force_dense", "dense_w"])
+@pytest.mark.parametrize("n", [700, 9000])
+def test_stateful_tick_on_general_and_dense_forms(q, form, n):
+    """the COMPLETE tick (planner state carried across ticks, swing trajectories, IK, joint PD, QP, J^T) on the
+    general 6x6 form and on the dense 12x12 form - forced on the reference's weights, and selected by a W that really is not
+    diagonal (balance_controller.hpp:76-77: W is the caller's) - tracks the oracle tick by tick like the uniform form does
+    (test_on_device_swing_planning_multi_tick).  700 robots: four lanes per robot; 9000: one lane per robot, Hessian planes in LDS."""
+    from oracle import c_oracle as O
+    from tests.test_oracle_cpu import _planned_batch
+
+    P = q.cheetah_params(0.6)
+    tune = {}
+    if form == "dense_w":
+        A = np.random.default_rng(3).normal(size=(12, 12))
+        P["W"] = P["W"] + 2e-6 * A @ A.T
+    else:
+        tune[form] = 1
+    ctl = q.BalanceController.from_params(P).set_tuning(**tune)
+    assert ctl.kernel_name == ("diagW-6x6" if form == "force_general" else "dense-12x12")
+    if form != "force_general":
+        assert ctl.query_launch(n, kin=True)["lanes_per_robot"] == (4 if n == 700 else 1)
+    dev_state = q.new_swing_states(n)
+    ref_state = O.new_swing_states(n)
+    for tick in range(0, 120, 12):
+        b = _planned_batch(n, tick)
+        o = ctl.control_batch_host(dict(b, swing_state=dev_state), want_torques=True)
+        ref = O.tick_planned_batch(P, b, ref_state, threads=8)
+        assert (o["status"] == 0).all()
+        assert np.array_equal(dev_state["leg_state"], ref_state["leg_state"]) and np.array_equal(dev_state["has_traj"], ref_state["has_traj"])
+        m = ref_state["has_traj"].repeat(3, axis=1) == 1
+        assert np.max(np.abs(dev_state["p_start"][m] - ref_state["p_start"][m])) < 1e-9
+        assert np.max(np.abs(dev_state["p_final"][m] - ref_state["p_final"][m])) < 1e-9
+        scale = np.maximum(1.0, np.abs(ref["grf_body"]).max(axis=1, keepdims=True))
+        assert np.max(np.abs(o["grf_body"] - ref["grf_body"]) / scale) < 1e-6, tick
+        assert np.max(np.abs(o["joint_tau"] - ref["joint_tau"])) < 2e-5, tick
+    assert (ref_state["has_traj"] == 1).any()
+
+
 def test_every_contact_pattern(q):
     """all 16 stance patterns (incl. a single foot and no foot on the ground) against the oracle"""
     from oracle import c_oracle as O

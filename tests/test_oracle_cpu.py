@@ -408,12 +408,13 @@ def test_pinv3_converges_on_an_exactly_rank_deficient_jacobian():
 
 
 def test_pinv_band_takes_its_rank_from_the_device_rule():
-    """ADVICE r4: inside the band where this build answers legJacobianInverse with the pseudo-inverse (|det| below
-    max(epsilon, 64 epsilon (sum |l|)^3)) the device's pinv3_apply never takes a third pivot and drops a second one below 1e-9
+    """ADVICE r4 / r5: inside the band where this build answers legJacobianInverse with the pseudo-inverse (|det| below
+    max(epsilon, 64 epsilon (sum |l|)^3)) the DEVICE's pinv3_apply never takes a third pivot and drops a second one below 1e-9
     of the first, while Armadillo's tolerance (3 sigma_max epsilon) would keep sigma_3 down to ~1e-16 sigma_1: for |det|
-    between ~1e-17 and the band's upper end the two would be a rank-2 and a rank-3 pseudo-inverse.  The granularity of the knee
-    cosine makes that window all but unreachable (test_inv_pinv_switch_has_numbers), but the checker must not lean on that:
-    oracle_pinv3_band takes the RANK from the device's rule and only the values from the SVD.  Planted matrices:"""
+    between ~1e-17 and the band's upper end the two are a rank-2 and a rank-3 pseudo-inverse.  oracle_pinv3_band restates the
+    device's rule (rank by complete pivoting, values from the SVD) so that the difference has numbers; oracle_swing_torque itself
+    applies arma::pinv's rule (oracle_pinv3) like the reference and COUNTS the legs on which the two rules disagree
+    (test_swing_torque_counts_pinv_rule_disagreements).  Planted matrices:"""
     eps = np.finfo(float).eps
     rng = np.random.default_rng(11)
     lo = max(eps, 64 * eps * 0.518 ** 3)
@@ -447,6 +448,36 @@ def test_pinv_band_takes_its_rank_from_the_device_rule():
         Ja, ok = O.pinv3(A)
         assert ok and rank == (2 if trial % 2 else 1)
         np.testing.assert_allclose(Jb, Ja, atol=1e-9 * max(1.0, np.abs(Ja).max()))
+
+
+def test_swing_torque_counts_pinv_rule_disagreements():
+    """ADVICE r5: the checker restates the reference (arma::pinv's tolerance), the device keeps its own rank rule, and every swing
+    leg on which the two would keep a different number of singular values is counted - so "the window is unreachable" is an
+    assertion the GPU tests make, not an assumption.  Here: out-of-reach and reachable swing references over random postures
+    leave the counter at 0 (IK produces exact rank loss or a regular J); a kinematic model engineered to put J inside the
+    window makes it fire."""
+    kin = O.default_kinematics()
+    rng = np.random.default_rng(5)
+    O.pinv_rule_disagreements(reset=True)
+    R = np.eye(3)
+    for trial in range(4000):
+        leg = trial % 4
+        far = trial % 3 == 0
+        pos = rng.normal(size=3) * (3.0 if far else 0.2) + np.array([0.0, 0.0, -0.25])
+        O.swing_torque(leg, R, np.zeros(3), pos, rng.normal(size=3), rng.uniform(-1, 1, 3), rng.normal(size=3), kin)
+    assert O.pinv_rule_disagreements() == 0
+    # the counter is alive: a hip offset of 1e-13 m and a far target 1e-10 m off the hip's roll axis - the stretched leg lies along that
+    # axis, the roll column of J is ~1e-10 of the pitch column: Armadillo's 3 sigma_max epsilon keeps it (rank 2), the device's
+    # "second pivot above 1e-9 of the first" does not (rank 1)
+    import copy
+
+    k2 = copy.deepcopy(kin)
+    k2.links[0] = 1e-13
+    for trial in range(200):
+        pos = np.array(k2.hip[0:3]) + np.array([5.0 if trial % 2 else -5.0, rng.normal() * 1e-10, rng.normal() * 1e-10])
+        O.swing_torque(0, R, np.zeros(3), pos, rng.normal(size=3), rng.uniform(-1, 1, 3), rng.normal(size=3), k2)
+    hits = O.pinv_rule_disagreements(reset=True)
+    assert hits > 150 and O.pinv_rule_disagreements() == 0
 
 
 def test_reference_inside_the_inner_reach_limit_gives_nan_torques():
