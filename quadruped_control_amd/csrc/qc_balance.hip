@@ -384,9 +384,12 @@ struct Lane {
 // swing edge, or any swinging leg on the very first call); if there is one, FootTrajectoryManager::
 // referenceStates(gait_map, bounds) (trajectory.cpp:308-344) CLEARS every stored trajectory and creates
 // those of the planned legs from p_start = Rwb foot + x (commander_node.cpp:456) and the planned foothold.
+// Returns the has_traj bits of this lane's legs after the update (bit = leg number): they travel in the robot's stance word (bits
+// 12-15) to the torque pass, which used to read them back - one agent-scope load per swing leg, of a record line the wave
+// already had - from memory.
 template <int FPL, bool STR = false>
-QC_DEV void swing_plan(CParams& P, const BatchIn& in, long robot, int foot0, uint32_t stance, const RawState& St, const Wrench<FPL>& W,
-                       const TickExtra& X) {
+QC_DEV uint32_t swing_plan(CParams& P, const BatchIn& in, long robot, int foot0, uint32_t stance, const RawState& St, const Wrench<FPL>& W,
+                           const TickExtra& X) {
   constexpr int GG = 4 / FPL;
   SwingState* S = in.swing_state + robot;
   const bool first = X.leg_state[0] < 0;  // state_map_.empty()
@@ -402,6 +405,7 @@ QC_DEV void swing_plan(CParams& P, const BatchIn& in, long robot, int foot0, uin
     if (swing_now && (first || prev == 1)) plan |= 1 << i;
   }
   const bool any = group_or<GG, STR>(plan) != 0;
+  uint32_t has_bits = 0u;
 #pragma unroll
   for (int i = 0; i < FPL; i++) {
     const int leg = foot0 + i;
@@ -415,9 +419,12 @@ QC_DEV void swing_plan(CParams& P, const BatchIn& in, long robot, int foot0, uin
         S->p_final[3 * leg + r] = fh[r];
       }
     }
-    S->has_traj[leg] = any ? ((plan >> i) & 1) : had[i];
+    const int has_now = any ? ((plan >> i) & 1) : had[i];
+    S->has_traj[leg] = has_now;
     S->leg_state[leg] = ((stance >> leg) & 1u) ? 1 : 0;
+    has_bits |= has_now ? (1u << leg) : 0u;
   }
+  return has_bits;
 }
 
 // the assembly of one robot (or of this lane's feet of it): wrench target and lever arms, contact state, optional
@@ -448,9 +455,9 @@ QC_DEV uint32_t assemble_from_state(CParams& P, const BatchIn& in, long robot, i
         // integer part of a double subtracts exactly, and fmod's result carries the sign of v (-1.0 -> -0.0; inf -> NaN both ways)
         const double v = phs[i] + step;
         phs[i] = __builtin_copysign(v - __builtin_trunc(v), v);
-        // every lane of the group computes the same four values; the first one stores them (read again, past
-        // the vector L1, by this wave's store phase for the swing trajectories)
-        if (member == 0) __hip_atomic_store(wp + i, phs[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // every lane of the group computes the same four values; the first one stores them (read again by this wave's
+        // store phase for the swing trajectories - workgroup scope, see swing_fetch)
+        if (member == 0) __hip_atomic_store(wp + i, phs[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     }
 #pragma unroll
@@ -461,7 +468,8 @@ QC_DEV uint32_t assemble_from_state(CParams& P, const BatchIn& in, long robot, i
       stance |= (ge0 && le) ? (1u << i) : 0u;
     }
   }
-  if (KIN && in.swing_state) swing_plan<FPL, STR>(P, in, robot, foot0, stance, S, W, X);
+  if (KIN && in.swing_state)  // (bits 12-15: has_traj per leg, for the torque pass; only member 0's word reaches the stock: the group's bits are or-ed)
+    stance |= (uint32_t)group_or<GG, STR>((int)swing_plan<FPL, STR>(P, in, robot, foot0, stance, S, W, X)) << 12;
   // non-finite inputs poison b, r or R: report QC_NOT_PD instead of iterating on NaNs
   const bool bad = group_or<GG, STR>(!(fin == 0.0) ? 1 : 0) != 0;
   if (bad) {
@@ -611,21 +619,26 @@ struct SwingIn {
   int leg, has;
   double q[3], qdot[3], x[3], a[3], b[3], ph;  // a, b: trajectory end points (swing_state) or reference position / velocity (swing_pos / swing_vel)
 };
-QC_DEV void swing_fetch(const BatchIn& in, long idx, int leg, SwingIn& T) {
+// (`stance_word`: the robot's stance word from the output stock - bits 12-15 carry has_traj as the assembly phase left it)
+QC_DEV void swing_fetch(const BatchIn& in, long idx, int leg, uint32_t stance_word, SwingIn& T) {
   T.idx = idx;
   T.leg = leg;
   T.has = 1;
   T.ph = 0.0;
   if (in.swing_state) {  // FootTrajectoryManager::referenceState(leg, phase), trajectory.cpp:360-388
     const SwingState* S = in.swing_state + idx;
-    // written by this wave's assembly phase: read past the (possibly stale) vector L1
-    T.has = __hip_atomic_load(&S->has_traj[leg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    T.has = (int)((stance_word >> (12 + leg)) & 1u);
+    // p_start / p_final / the advanced phases may have been written by THIS wave's assembly phase (another lane of it): workgroup
+    // scope is all that takes - one wave, one CU, one write-through vector L1, a barrier's release / acquire in between.  Rounds 4-5
+    // used agent scope here, which on this multi-die part means "visible across XCDs": every one of the four 8-byte phase stores
+    // went out as its own write-through (WRITE_SIZE 1.40x the bytes written: profiles/r06a_tick_full262144) and every load
+    // bypassed the L1 that held the line.
 #pragma unroll
     for (int r = 0; r < 3; r++) {
-      T.a[r] = __hip_atomic_load(&S->p_start[3 * leg + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      T.b[r] = __hip_atomic_load(&S->p_final[3 * leg + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      T.a[r] = __hip_atomic_load(&S->p_start[3 * leg + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      T.b[r] = __hip_atomic_load(&S->p_final[3 * leg + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    T.ph = in.gait_dt ? __hip_atomic_load(in.gait_phase + 4 * idx + leg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : in.gait_phase[4 * idx + leg];
+    T.ph = in.gait_dt ? __hip_atomic_load(in.gait_phase + 4 * idx + leg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : in.gait_phase[4 * idx + leg];
   } else {
 #pragma unroll
     for (int r = 0; r < 3; r++) {
@@ -768,7 +781,8 @@ QC_DEV void torque_pass(const DevParams* __restrict__ Pg, const BatchIn& in, con
   if (lane < ns) {  // the first swing pass's inputs: in flight while the stance legs are computed
     const int code = tl[lane];
     nslot = code >> 2;
-    swing_fetch(in, __double_as_longlong(sout[OUT_IDX * SP + nslot]), code & 3, nxt);
+    swing_fetch(in, __double_as_longlong(sout[OUT_IDX * SP + nslot]), code & 3,
+                (uint32_t)((unsigned long long)__double_as_longlong(sout[OUT_WORD * SP + nslot]) >> 32), nxt);
   }
   asm volatile("" ::: "memory");  // (... and requested above this line, not behind the stance legs' arithmetic)
   QC_CLK_ABS(13, 15);
@@ -794,7 +808,8 @@ QC_DEV void torque_pass(const DevParams* __restrict__ Pg, const BatchIn& in, con
     if (t + 64 < ns) {  // the next pass's inputs are requested before this pass computes
       const int code = tl[t + 64];
       nslot = code >> 2;
-      swing_fetch(in, __double_as_longlong(sout[OUT_IDX * SP + nslot]), code & 3, nxt);
+      swing_fetch(in, __double_as_longlong(sout[OUT_IDX * SP + nslot]), code & 3,
+                  (uint32_t)((unsigned long long)__double_as_longlong(sout[OUT_WORD * SP + nslot]) >> 32), nxt);
     }
     double R[9];
     task_rwb<SP, RLDS>(in, Rplanes, cslot, cur.idx, R);

@@ -591,12 +591,12 @@ def test_fused_tick_on_general_and_dense_forms(q, monkeypatch, force):
 
 
 @pytest.mark.parametrize("form", ["force_general", "force_dense", "dense_w"])
-@pytest.mark.parametrize("n", [700, 9000])
+@pytest.mark.parametrize("n", [700, 40000])
 def test_stateful_tick_on_general_and_dense_forms(q, form, n):
     """the COMPLETE tick (planner state carried across ticks, swing trajectories, IK, joint PD, QP, J^T) on the
     general 6x6 form and on the dense 12x12 form - forced on the reference's weights, and selected by a W that really is not
     diagonal (balance_controller.hpp:76-77: W is the caller's) - tracks the oracle tick by tick like the uniform form does
-    (test_on_device_swing_planning_multi_tick).  700 robots: four lanes per robot; 9000: one lane per robot, Hessian planes in LDS."""
+    (test_on_device_swing_planning_multi_tick).  700 robots: four lanes per robot; 40 000: one lane per robot, Hessian planes in LDS."""
     from oracle import c_oracle as O
     from tests.test_oracle_cpu import _planned_batch
 
