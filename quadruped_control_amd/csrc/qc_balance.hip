@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -44,8 +45,9 @@ namespace qc {
 // (MODE 0) restocks 64 robots at a time, a one-fill wave (MODE 1/2) only ever holds its 64/G robots, so its
 // stock is 64/G slots - 9.2 KB instead of 18 KB at G = 2, which is what lets more than two workgroups per
 // SIMD share the CU's 160 KB (the 92-VGPR one-fill kernels are register-good for five).
-// "this robot still has its polish release" (Lane::iterate): bit 9 of the stance word wherever a robot travels (stock, hand-over
-// records); inside a lane it is the sign of the lane's multiplier tolerance `tol_s`
+// "this robot still has its polish release" (Lane::iterate): bit 9 of the stance word in the hand-over records of a RUNNING robot
+// (re-pack areas, the paired waves' list); inside a lane it is the sign of the lane's multiplier tolerance `tol_s`, and a fresh
+// robot starts from DevParams::tol_start
 constexpr uint32_t QC_POLISH_ONE = 1u << 9;
 enum { IN_B = 0, IN_R = 6, IN_FLAGS = 18, IN_IDX = 19, IN_PLANES = 20,
        OUT_F = 0, OUT_STAT = 12, OUT_WORD = 13, OUT_IDX = 14, OUT_PLANES = 15,
@@ -272,7 +274,7 @@ struct Lane {
   }
 
   // take the robot staged in `slot` of the wave's input stock into this lane's group
-  // (`tol` = DevParams::tol_d)
+  // (`tol` = DevParams::tol_start: a fresh robot has its polish release unless the handle switched the polish off)
   template <int SP>
   QC_DEV void load_from_stock(const double* __restrict__ sin, int slot, int member, double tol) {
     foot0 = member * FPL;
@@ -288,8 +290,8 @@ struct Lane {
 #pragma unroll
       for (int k = 0; k < 3; k++) Wr.r[i][k] = sin[(IN_R + 3 * (foot0 + i) + k) * SP + slot];
     const unsigned long long fl = (unsigned long long)__double_as_longlong(sin[IN_FLAGS * SP + slot]);
-    stance = (uint32_t)fl & ~QC_POLISH_ONE;
-    tol_s = Eqp::kTolScale * (((uint32_t)fl & QC_POLISH_ONE) ? tol : -tol);
+    stance = (uint32_t)fl;
+    tol_s = Eqp::kTolScale * tol;
     const uint32_t wv = (uint32_t)(fl >> 32);
     idx = __double_as_longlong(sin[IN_IDX * SP + slot]);
     const bool use_warm = (wv & 0x80000000u) != 0;
@@ -321,8 +323,8 @@ struct Lane {
     for (int i = 0; i < FPL; i++)
 #pragma unroll
       for (int k = 0; k < 3; k++) Wr.r[i][k] = W.r[i][k];
-    stance = st & ~QC_POLISH_ONE;
-    tol_s = Eqp::kTolScale * ((st & QC_POLISH_ONE) ? tol : -tol);
+    stance = st;
+    tol_s = Eqp::kTolScale * tol;
     idx = robot;
     const bool use_warm = (wv & 0x80000000u) != 0;
 #pragma unroll
@@ -479,7 +481,7 @@ QC_DEV uint32_t assemble_from_state(CParams& P, const BatchIn& in, long robot, i
 #pragma unroll
     for (int i = 0; i < FPL; i++) W.r[i][0] = W.r[i][1] = W.r[i][2] = 0.0;
   }
-  return stance | (P.polish != 0 ? QC_POLISH_ONE : 0u);  // "still has its polish release" travels in the stance word
+  return stance;
 }
 
 template <bool KIN, int FPL, bool STR>
@@ -1020,12 +1022,46 @@ QC_DEV int clamp_steps_for(CParams& P, const uint32_t* warm) {
 // fill (chunk <= 64 / G).  MODE 2: one fill and the SIMD to itself, recalculation constants resident in VGPRs.
 // RACE (strided 4-lane one-fill kernels): strategies racing per robot, 1, 2 or 4; a wave then holds 16 / RACE robots (see Lane).
 
+// The kernel's argument block as the launch lays it out (kernarg segment), for re-deriving BatchIn / BatchOut AT THEIR USE in the
+// joint_q kernels: 23 array pointers held in SGPRs from the kernel's entry to its flush - across a solve that needs none of
+// them - do not fit the 102-SGPR file next to the loop's masks, and the compiler parks them in VGPR lanes (108-175 spilled
+// SGPRs, ~250 v_readlane per wave: profiles/r05_kernel_resources.txt).  Read again from the (constant, scalar-cached) kernarg
+// segment where they are used, behind an opaque pointer so that they are not kept live in between, they cost a few s_loads.
+struct BalanceKernelArgs {
+  const DevParams* Pg;
+  long n;
+  BatchIn in;
+  const uint32_t* warm;
+  BatchOut out;
+  long chunk;
+  int refill_t;
+};
+template <class T>
+QC_DEV const T& kernarg_here(unsigned off) {
+  const __attribute__((address_space(4))) char* p = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+  p += off;
+  asm volatile("" : "+s"(p));
+  return *(const T*)(const __attribute__((address_space(4))) T*)p;
+}
+
 template <class Eqp, bool KIN, int MIN_WAVES_PER_SIMD, int MODE = 0, int RACE = 1>
-__global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const DevParams* __restrict__ Pg, const long n, const BatchIn in,
-                                                                         const uint32_t* __restrict__ warm, const BatchOut out, const long chunk,
+__global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const DevParams* __restrict__ Pg, const long n, const BatchIn in_k,
+                                                                         const uint32_t* __restrict__ warm, const BatchOut out_k, const long chunk,
                                                                          const int refill_t) {
   static_assert(RACE == 1 || (MODE != 0 && Eqp::kStrided && Eqp::G == 4), "racing strategies exist for the strided one-fill kernels");
   constexpr int G = Eqp::G;
+  // (KIN: re-read from the kernarg segment at every use, see BalanceKernelArgs; the QP-only kernels hold 14 pointers and keep them,
+  // and so does the one-wave-per-SIMD kernel of chain-bound batches - a lone wave waits out every scalar-load round trip: the fused
+  // tick on 4 096 robots 27.36 -> 27.55 us with it, profiles/r06_tick_ab.log)
+  constexpr bool REREAD = KIN && MODE != 2;
+  auto IN = [&]() -> const BatchIn& {
+    if constexpr (REREAD) return kernarg_here<BatchIn>((unsigned)offsetof(BalanceKernelArgs, in));
+    else return in_k;
+  };
+  auto OUT = [&]() -> const BatchOut& {
+    if constexpr (REREAD) return kernarg_here<BatchOut>((unsigned)offsetof(BalanceKernelArgs, out));
+    else return out_k;
+  };
   extern __shared__ __attribute__((aligned(16))) double qc_lds[];  // [stock planes][64] (+ the dense form's 78 Hessian planes)
   constexpr int SP = stock_slots(G, MODE) + 1;  // plane stride of this mode's stock
   // One-lane dense form as one-fill workgroups (round 5): the 78 Hessian planes (39 936 B) ARE the workgroup's LDS - four
@@ -1095,7 +1131,7 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
         // (behind wave-uniform null tests), then the 48 doubles of the state - and nothing dependent sits in between: a
         // wave's fill used to chain four to five vector-memory round trips (two batches of state, contact bytes, warm word,
         // Rwb again: 2.5 us from kernel entry to "inputs landed" for a lone wave, profiles/r03_timeline.log).
-        const BatchIn& ia = in;
+        const BatchIn& ia = IN();
         const uint32_t* wp = warm;
         const long robot = cursor + lane;
         const uint32_t sw = ia.stance ? *reinterpret_cast<const uint32_t*>(ia.stance + 4 * robot) : 0u;
@@ -1113,7 +1149,7 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
 #pragma unroll
           for (int k = 0; k < 9; k++) sin[k * SP + lane] = S.R[k];
         }
-        L.load_direct(W, st, wv, robot, 0, P.tol_d);
+        L.load_direct(W, st, wv, robot, 0, P.tol_start);
       } else if constexpr (TWIN) {
         // The wave-uniform loops below run every lane through the recalculation body, the lanes beyond a ragged last fill
         // included: they carry a defined robot - no wrench, no stance foot (every foot eliminated, nothing to iterate on) -
@@ -1127,7 +1163,7 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
         L.load_direct(W, 0u, 0u, -1, 0, 0.0);
       }
     } else {
-      stock_n = restock<G, KIN, STR, SP>(Pg, in, warm, cursor, end, lane, member, sin);
+      stock_n = restock<G, KIN, STR, SP>(Pg, IN(), warm, cursor, end, lane, member, sin);
     }
     const int grp = lane_group<G, STR>(lane);
     busy = grp < stock_n;
@@ -1153,8 +1189,8 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
         L.drop_all = sid == 1 || sid == 2;
       }
       double tol0;  // (RESIDENT: from the register copy - another scalar load here is a memory round trip a lone wave waits out)
-      if constexpr (RESIDENT) tol0 = uc.tol_d;
-      else tol0 = QC_PARAMS_HERE(Pg)->tol_d;
+      if constexpr (RESIDENT) tol0 = uc.tol_start;
+      else tol0 = QC_PARAMS_HERE(Pg)->tol_start;
       L.template load_from_stock<SP>(sin, busy ? slot : 0, member, tol0);
       eqp.setup(*QC_PARAMS_HERE(Pg), L.Wr, L.foot0);
       busy = busy && !probe;
@@ -1221,19 +1257,19 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
         QC_CLK(7, 8);
         if (slot < stock_n && sid == win) L.template push_result<SP>(sout, slot);
         __syncthreads();
-        flush_out<Eqp::G, KIN, STR, SP>(Pg, in, out, sout, stock_n, lane);
+        flush_out<Eqp::G, KIN, STR, SP>(Pg, IN(), OUT(), sout, stock_n, lane);
         QC_CLK_END(8);
         return;
       }
       QC_CLK(7, 8);
       if (grp < stock_n) L.template push_result<SP>(sout, grp);
       __syncthreads();
-      flush_out<Eqp::G, KIN, STR, SP>(Pg, in, out, sout, stock_n, lane);
+      flush_out<Eqp::G, KIN, STR, SP>(Pg, IN(), OUT(), sout, stock_n, lane);
       QC_CLK_END(8);
       return;
     }
     if (busy || TWIN) {  // (TWIN: the shadow lanes of a ragged fill get their Hessian column too)
-      if constexpr (!DIRECT) L.template load_from_stock<SP>(sin, grp, member, QC_PARAMS_HERE(Pg)->tol_d);
+      if constexpr (!DIRECT) L.template load_from_stock<SP>(sin, grp, member, QC_PARAMS_HERE(Pg)->tol_start);
       eqp.setup(*QC_PARAMS_HERE(Pg), L.Wr, L.foot0);
     }
     const bool mine = busy;
@@ -1288,7 +1324,7 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
         // are still being read; Rwb comes from memory) - their registers are about to carry somebody else's robot
         if (mine && !busy) {
           CParams& P = *QC_PARAMS_HERE(Pg);
-          store_result<KIN, 4, false>(P, in, out, L.idx, L.stance, L.status, L.iters, L.word_bits() | 0x80000000u, L.f, 0);
+          store_result<KIN, 4, false>(P, IN(), OUT(), L.idx, L.stance, L.status, L.iters, L.word_bits() | 0x80000000u, L.f, 0);
           role = 0;
         }
         const int nb = __builtin_popcountll(bm);
@@ -1374,7 +1410,7 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
       const bool store_own = (role & 1) && !(partner != lane && twin_won);
       if (store_own || (role & 6) == 6) {  // straight from the registers, like the lanes that finished before the fork: no output stock on this path
         CParams& P = *QC_PARAMS_HERE(Pg);
-        store_result<KIN, 4, false>(P, in, out, L.idx, L.stance, L.status, L.iters, L.word_bits() | 0x80000000u, L.f, 0);
+        store_result<KIN, 4, false>(P, IN(), OUT(), L.idx, L.stance, L.status, L.iters, L.word_bits() | 0x80000000u, L.f, 0);
       }
       QC_CLK_END(8);
       return;
@@ -1392,7 +1428,7 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
     }
     QC_CLK(7, 8);
     __syncthreads();
-    flush_out<Eqp::G, KIN, STR, SP, RPARK>(Pg, in, out, sout, stock_n, lane, RPARK ? sin : nullptr);
+    flush_out<Eqp::G, KIN, STR, SP, RPARK>(Pg, IN(), OUT(), sout, stock_n, lane, RPARK ? sin : nullptr);
     QC_CLK_END(8);
     return;
   }
@@ -1400,7 +1436,7 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
   // inside the loop) it needs no spills: batches that fit one fill per wave
   // never execute the in-loop copy.
   if (cursor < end) {
-    stock_n = restock<G, KIN, false, SP>(Pg, in, warm, cursor, end, lane, member, sin);
+    stock_n = restock<G, KIN, false, SP>(Pg, IN(), warm, cursor, end, lane, member, sin);
     cursor += stock_n;
   }
   QC_CLK(0, 1);
@@ -1410,7 +1446,7 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
     const long avail = (end - cursor) + (long)(stock_n - stock_next);
     if (avail > 0 && (n_free >= refill_t || busy_mask == 0)) {
       if (stock_next == stock_n) {
-        stock_n = restock<G, KIN, false, SP>(Pg, in, warm, cursor, end, lane, member, sin);
+        stock_n = restock<G, KIN, false, SP>(Pg, IN(), warm, cursor, end, lane, member, sin);
         stock_next = 0;
         cursor += stock_n;
       }
@@ -1418,7 +1454,7 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
       const int take = n_free < have ? n_free : have;
       const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(~busy_mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)~busy_mask, 0)) / G;
       if (!busy && rank < take) {
-        L.template load_from_stock<SP>(sin, stock_next + rank, member, QC_PARAMS_HERE(Pg)->tol_d);
+        L.template load_from_stock<SP>(sin, stock_next + rank, member, QC_PARAMS_HERE(Pg)->tol_start);
         CParams& P = *QC_PARAMS_HERE(Pg);
         eqp.setup(P, L.Wr, L.foot0);
         busy = true;
@@ -1442,7 +1478,7 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
       const int n_fin = __builtin_popcountll(fin_mask) / G;
       if (out_n + n_fin > 64) {  // dense flush of the output stock, one robot per lane
         __syncthreads();
-        flush_out<Eqp::G, KIN, false, SP>(Pg, in, out, sout, out_n, lane);
+        flush_out<Eqp::G, KIN, false, SP>(Pg, IN(), OUT(), sout, out_n, lane);
         __syncthreads();
         out_n = 0;
       }
@@ -1456,7 +1492,7 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
   }
   __syncthreads();
   QC_CLK(1, 8);
-  flush_out<Eqp::G, KIN, false, SP>(Pg, in, out, sout, out_n, lane);
+  flush_out<Eqp::G, KIN, false, SP>(Pg, IN(), OUT(), sout, out_n, lane);
   QC_CLK_END(8);
 }
 
@@ -1543,7 +1579,7 @@ __global__ __launch_bounds__(128, 2) void balance_pair_kernel(const DevParams* _
       const uint32_t st = assemble_from_state<KIN, 4, false>(P, in, robot, 0, S, fp, sw, X, W);
 #pragma unroll
       for (int k = 0; k < 9; k++) lds.Rrows[9 * slot + k] = S.R[k];
-      L.load_direct(W, st, wv, robot, 0, P.tol_d);
+      L.load_direct(W, st, wv, robot, 0, P.tol_start);
       eqp.setup(P, L.Wr, 0);
       busy = P.max_iter != 0;  // (0: the batch-load probe - load -> assemble -> store only)
     }
@@ -2243,6 +2279,7 @@ int qc_create_abi(const qc_params* p, int device, qc_handle** out, int abi_versi
   // 1e-12 gave 0.2 N = 2e-3 relative in the parameter fuzz; 1e-13 ... 1e-15 all agree with the NNLS restatement
   // and change neither the recalculation counts of 1 M robots nor anything else measurable).
   d.tol_d = 1e-14;
+  d.tol_start = d.tol_d;  // (polish on)
   d.max_iter = p->max_iter > 0 ? p->max_iter : 200;
   h->cfg_max_iter = d.max_iter;
   d.clamp_steps = 0;  // 0: per kernel (clamp_steps_for)
@@ -2304,14 +2341,18 @@ int qc_set_tuning(qc_handle* h, const char* key, double value) {
     (k == "force_general" ? h->force_general : h->force_dense) = value != 0;
     h->diag_w = h->cfg_diag_w && !h->force_dense;
     h->uniform = h->cfg_uniform && !h->force_general;
-  } else if (k == "tol_d") { h->dp.tol_d = value; params = true; }
+  } else if (k == "tol_d") { h->dp.tol_d = value; h->dp.tol_start = h->dp.polish ? value : -value; params = true; }
   else if (k == "max_iter") {  // <= 0: back to the handle's own cap (qc_params.max_iter)
     if (value > (double)QC_MAX_ITER_LIMIT) return fail(QC_ERR_INVALID, "qc_set_tuning: max_iter must be <= 65535");
     h->probing = false;
     h->dp.max_iter = value > 0 ? (int)value : h->cfg_max_iter; params = true;
   }
   else if (k == "clamp_steps") { h->dp.clamp_steps = value >= 1 ? (int)value : 0; params = true; }
-  else if (k == "polish") { h->dp.polish = value != 0 ? 1 : 0; params = true; }  // 0: round 5's acceptance rule
+  else if (k == "polish") {  // 0: round 5's acceptance rule
+    h->dp.polish = value != 0 ? 1 : 0;
+    h->dp.tol_start = h->dp.polish ? h->dp.tol_d : -h->dp.tol_d;
+    params = true;
+  }
   else if (k == "probe_batch_load") {
     // measurement probe: load -> assemble -> store only (every robot reports QC_MAX_ITER); 0 restores the handle's own cap
     h->probing = value != 0;

@@ -71,6 +71,7 @@ struct DevParams {
   double traj_basis[21];  // [power j][k]: column k of A^-1 of the sextic system (trajectory.cpp:256-277), k = start, final, centre
   double stance_phase; // gait.cpp:45, default duty of the on-device contact rule
   double tol_d;        // relative multiplier tolerance
+  double tol_start;    // what a fresh robot starts with: +tol_d with the polish at acceptance on (DevParams::polish), -tol_d with it off
   int max_iter;
   int clamp_steps;     // clamp steps a fresh robot takes before its first ratio test (one-fill kernels)
   int tail_race;       // the 4-lane tail races two drop rules on its last <= 8 robots
@@ -101,13 +102,13 @@ typedef const __attribute__((address_space(4))) DevParams CParams;
 // copy (VGPRs, pinned): used by the one-wave-per-SIMD launch of small batches, where a scalar load + wait at the
 // top of every recalculation is exposed latency (no second wave to hide it) and the VGPR budget is 512.
 struct UConst {
-  double mu, fzmin, fzmax, inv_w_u, w_u, tol_d;
+  double mu, fzmin, fzmax, inv_w_u, w_u, tol_start;
   double inv_bz_u[3], Vd[6];
   int max_iter;
 };
 QC_DEV UConst load_uconst(CParams& P) {
   UConst u;
-  u.mu = P.mu; u.fzmin = P.fzmin; u.fzmax = P.fzmax; u.inv_w_u = P.inv_w_u; u.w_u = P.w_u; u.tol_d = P.tol_d;
+  u.mu = P.mu; u.fzmin = P.fzmin; u.fzmax = P.fzmax; u.inv_w_u = P.inv_w_u; u.w_u = P.w_u; u.tol_start = P.tol_start;
 #pragma unroll
   for (int k = 0; k < 3; k++) u.inv_bz_u[k] = P.inv_bz_u[k];
 #pragma unroll
@@ -117,7 +118,7 @@ QC_DEV UConst load_uconst(CParams& P) {
 }
 // keeps the copy where it is (in VGPRs) instead of letting the compiler re-load it from the constant buffer
 QC_DEV void pin_uconst(UConst& u) {
-  asm volatile("" : "+v"(u.mu), "+v"(u.fzmin), "+v"(u.fzmax), "+v"(u.inv_w_u), "+v"(u.w_u), "+v"(u.tol_d));
+  asm volatile("" : "+v"(u.mu), "+v"(u.fzmin), "+v"(u.fzmax), "+v"(u.inv_w_u), "+v"(u.w_u), "+v"(u.tol_start));
   asm volatile("" : "+v"(u.inv_bz_u[0]), "+v"(u.inv_bz_u[1]), "+v"(u.inv_bz_u[2]));
   asm volatile("" : "+v"(u.Vd[0]), "+v"(u.Vd[1]), "+v"(u.Vd[2]), "+v"(u.Vd[3]), "+v"(u.Vd[4]), "+v"(u.Vd[5]), "+v"(u.max_iter));
 }
