@@ -1101,7 +1101,11 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
   const int member = lane_member<G, STR>(lane);
   int stock_n = 0, stock_next = 0;  // input stock: slots [stock_next, stock_n) hold assembled robots
   int out_n = 0;                    // output stock: slots [0, out_n) hold finished results
-  constexpr bool TWIN = Eqp::kHessianInLds && MODE != 0 && !KIN;  // one-lane dense form: stragglers fork into idle lanes with the other drop rule
+  // one-lane dense form, QP only: stragglers fork into idle lanes with the other drop rule.  (Not the joint_q kernel: with the results
+  // parked in the lanes' own dead Hessian columns for the torque pass - tools/experiments/r06_dense_kin_twin.patch - the race bought its
+  // tick nothing, 151.4 us with it, 151.4 with race = 0, 147.8 without the machinery: profiles/r06_dense_tick.log.  That kernel's time
+  // is its fill and flush at one wave per SIMD, not its stragglers.)
+  constexpr bool TWIN = Eqp::kHessianInLds && MODE != 0 && !KIN;
   Lane<Eqp, KIN, (RACE > 1) || TWIN> L;
   L.idx = -1;
   L.foot0 = member * (4 / G);
@@ -1301,10 +1305,11 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
       // The one-lane dense form has no 4-lane tail (the exchange tile of the 4-lane dense body does not fit next to the Hessian
       // planes), so a wave walks its one-lane body until its slowest robot is done - at half the lanes or fewer busy for most of
       // that walk.  Those idle lanes race: once at most 32 robots still run, every running robot is copied into an idle lane
-      // (working set, point, c, its 78 Hessian entries from the owner's LDS column to the twin's) which continues with the OTHER
-      // drop rule - all negative multipliers at once instead of the most negative one - and whoever reaches the KKT point first
-      // ends both (the tail race of the 6x6 forms, profiles/r02_tail_race_scan.log, with lanes instead of lane groups).  Cold
-      // batches only: a warm-started robot that is not done after its first recalculation is a face or two away.
+      // (working set, point, c; the 78 Hessian entries are READ from the owner's LDS column by both - nobody writes them after
+      // setup) which continues with the OTHER drop rule - all negative multipliers at once instead of the most negative one -
+      // and whoever reaches the KKT point first ends both (the tail race of the 6x6 forms, profiles/r02_tail_race_scan.log, with
+      // lanes instead of lane groups).  Cold batches only: a warm-started robot that is not done after its first recalculation
+      // is a face or two away.
       unsigned long long bm = __builtin_amdgcn_ballot_w64(busy);
       const bool fork_ok = warm == nullptr && QC_PARAMS_HERE(Pg)->tail_race != 0;
       // (both loops are wave-uniform and run every lane with `live` = busy - see Lane::iterate on why a finished or empty lane may
@@ -1381,10 +1386,8 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
             const uint32_t fb = wbits >> (6 * i);
             L.C.sx[i] = dec2(fb); L.C.sy[i] = dec2(fb >> 2); L.C.sz[i] = dec2(fb >> 4);
           }
-          // the robot's Hessian: the owner's LDS column -> this lane's (the owner only reads its column from here on)
-          const double* from = eqp.Qs - lane + partner;
-#pragma unroll 6
-          for (int k = 0; k < 78; k++) eqp.Qs[k * 64] = from[k * 64];
+          // the robot's Hessian: the twin reads the owner's LDS column (read-only after setup; same address in both lanes = a broadcast)
+          eqp.Qs = eqp.Qs - lane + partner;
           role = 2;
           busy = true;
         }
