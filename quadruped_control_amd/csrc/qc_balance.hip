@@ -55,6 +55,16 @@ enum { IN_B = 0, IN_R = 6, IN_FLAGS = 18, IN_IDX = 19, IN_PLANES = 20,
 constexpr int stock_slots(int G, int MODE) { return MODE == 0 ? 64 : 64 / G; }
 constexpr int TASK_DOUBLES = 32;  // 256 one-byte (robot, leg) tasks of the torque pass, behind the planes
 constexpr int stock_doubles(int slots) { return ((STOCK_PLANES * (slots + 1) + TASK_DOUBLES + 63) / 64) * 64; }
+// QPARK - the one-lane one-fill joint_q kernels of the 6x6 forms (round 6).  The torque pass needs every robot's twelve joint angles a
+// second time, tens of microseconds after the fill read them - by then the wave's lines have left the XCD's 4 MB L2 (a resident round of
+// workgroups streams 16 MB through it), so they came from the fabric again: 96 B per robot on top of the algorithmic bytes
+// (profiles/r06b_tick_full262144: FETCH 1.15x).  They are parked in LDS instead, twelve planes next to the nine of Rwb.  The room: the
+// re-pack records of the 4-lane tail move UNDER the output stock (nobody parks a result before the last record has been read:
+// finish_on_four_lanes<HOLD>, and the lanes that finished on the one-lane body push after the tail), which frees the input-stock area:
+//   [0, 9) Rwb   [9, 21) joint_q   [21, 36) output stock (= re-pack records during the tail)   + the task bytes
+// 36 x 65 + 32 doubles = 19 KB: eight workgroups per CU still fit the 160 KB.
+constexpr int QPARK_R = 0, QPARK_Q = 9, QPARK_OUT = 21, QPARK_PLANES = 36;
+constexpr int qpark_doubles() { return ((QPARK_PLANES * 65 + TASK_DOUBLES + 63) / 64) * 64; }
 
 // RACE (mode-2 kernels of batches that leave most SIMDs idle): several lane groups solve the SAME robot with
 // different pivoting strategies and the first to reach the KKT point wins.  A strategy is (nclamp, drop_all):
@@ -622,7 +632,8 @@ struct SwingIn {
   double q[3], qdot[3], x[3], a[3], b[3], ph;  // a, b: trajectory end points (swing_state) or reference position / velocity (swing_pos / swing_vel)
 };
 // (`stance_word`: the robot's stance word from the output stock - bits 12-15 carry has_traj as the assembly phase left it)
-QC_DEV void swing_fetch(const BatchIn& in, long idx, int leg, uint32_t stance_word, SwingIn& T) {
+// (`qslot` != nullptr - QPARK: the robot's parked joint angles, entry k at qslot[k * qstride])
+QC_DEV void swing_fetch(const BatchIn& in, long idx, int leg, uint32_t stance_word, SwingIn& T, const double* __restrict__ qslot = nullptr, int qstride = 0) {
   T.idx = idx;
   T.leg = leg;
   T.has = 1;
@@ -650,7 +661,7 @@ QC_DEV void swing_fetch(const BatchIn& in, long idx, int leg, uint32_t stance_wo
   }
 #pragma unroll
   for (int r = 0; r < 3; r++) {
-    T.q[r] = in.joint_q[12 * idx + 3 * leg + r];
+    T.q[r] = qslot ? qslot[(3 * leg + r) * qstride] : in.joint_q[12 * idx + 3 * leg + r];
     T.qdot[r] = in.joint_qdot[12 * idx + 3 * leg + r];
     T.x[r] = in.x[3 * idx + r];
   }
@@ -697,8 +708,9 @@ struct TorquePre {
 // four legs while 60 lanes idle (measured: +2 us on the 4 096-robot fused tick).
 template <int G>
 QC_DEV bool torque_by_group(int out_n) { return G > 1 && out_n <= 64 / G; }
+// (`Qplanes` != nullptr - QPARK: the joint angles parked by the fill, plane k of slot s at Qplanes[k * SP + s])
 template <int SP, int G, bool STR>
-QC_DEV void torque_prefetch(const BatchIn& in, const double* __restrict__ sout, int out_n, int lane, TorquePre& T) {
+QC_DEV void torque_prefetch(const BatchIn& in, const double* __restrict__ sout, int out_n, int lane, TorquePre& T, const double* __restrict__ Qplanes = nullptr) {
   // (defined in every lane and on both paths: an array written to different extents on two paths stays in memory - scratch)
 #pragma unroll
   for (int k = 0; k < 12; k++) T.q[k] = 0.0;
@@ -712,10 +724,15 @@ QC_DEV void torque_prefetch(const BatchIn& in, const double* __restrict__ sout, 
       for (int k = 0; k < 3 * FPL; k++) T.q[k] = qp[k];
     }
   } else if (lane < out_n) {
-    const long idx = __double_as_longlong(sout[OUT_IDX * SP + lane]);
-    const double* qp = in.joint_q + 12 * idx;
+    if (Qplanes) {  // (wave-uniform)
 #pragma unroll
-    for (int k = 0; k < 12; k++) T.q[k] = qp[k];
+      for (int k = 0; k < 12; k++) T.q[k] = Qplanes[k * SP + lane];
+    } else {
+      const long idx = __double_as_longlong(sout[OUT_IDX * SP + lane]);
+      const double* qp = in.joint_q + 12 * idx;
+#pragma unroll
+      for (int k = 0; k < 12; k++) T.q[k] = qp[k];
+    }
   }
 }
 // the stance-leg torque map of NL legs of the robot in `slot`, from leg0 on (their joint angles in q[0 .. 3 NL))
@@ -755,7 +772,7 @@ QC_DEV void stance_legs(CParams& P, const BatchIn& in, const BatchOut& out, cons
 }
 template <int SP, bool RLDS, int G, bool STR>
 QC_DEV void torque_pass(const DevParams* __restrict__ Pg, const BatchIn& in, const BatchOut& out, const double* __restrict__ sout, int out_n, int lane,
-                        const double* __restrict__ Rplanes, TorquePre& Q) {
+                        const double* __restrict__ Rplanes, TorquePre& Q, const double* __restrict__ Qplanes = nullptr) {
   QC_CLK_ABS(8, 13);
   unsigned char* const tl = reinterpret_cast<unsigned char*>(const_cast<double*>(sout) + OUT_PLANES * SP);  // (TASK_DOUBLES behind the planes)
   const bool have_swing = in.swing_pos || in.swing_state;
@@ -784,7 +801,7 @@ QC_DEV void torque_pass(const DevParams* __restrict__ Pg, const BatchIn& in, con
     const int code = tl[lane];
     nslot = code >> 2;
     swing_fetch(in, __double_as_longlong(sout[OUT_IDX * SP + nslot]), code & 3,
-                (uint32_t)((unsigned long long)__double_as_longlong(sout[OUT_WORD * SP + nslot]) >> 32), nxt);
+                (uint32_t)((unsigned long long)__double_as_longlong(sout[OUT_WORD * SP + nslot]) >> 32), nxt, Qplanes ? Qplanes + nslot : nullptr, SP);
   }
   asm volatile("" ::: "memory");  // (... and requested above this line, not behind the stance legs' arithmetic)
   QC_CLK_ABS(13, 15);
@@ -811,7 +828,7 @@ QC_DEV void torque_pass(const DevParams* __restrict__ Pg, const BatchIn& in, con
       const int code = tl[t + 64];
       nslot = code >> 2;
       swing_fetch(in, __double_as_longlong(sout[OUT_IDX * SP + nslot]), code & 3,
-                  (uint32_t)((unsigned long long)__double_as_longlong(sout[OUT_WORD * SP + nslot]) >> 32), nxt);
+                  (uint32_t)((unsigned long long)__double_as_longlong(sout[OUT_WORD * SP + nslot]) >> 32), nxt, Qplanes ? Qplanes + nslot : nullptr, SP);
     }
     double R[9];
     task_rwb<SP, RLDS>(in, Rplanes, cslot, cur.idx, R);
@@ -823,11 +840,11 @@ QC_DEV void torque_pass(const DevParams* __restrict__ Pg, const BatchIn& in, con
 // store the robots parked in the output stock: one per lane, or one per lane group when there are few
 template <int G, bool KIN, bool STR, int SP, bool RLDS = false>
 QC_DEV void flush_out(const DevParams* __restrict__ Pg, const BatchIn& in, const BatchOut& out, const double* __restrict__ sout, int out_n, int lane,
-                      const double* __restrict__ Rplanes = nullptr) {
+                      const double* __restrict__ Rplanes = nullptr, const double* __restrict__ Qplanes = nullptr) {
   TorquePre tq;
   if constexpr (KIN) {
     if (out.joint_tau) {
-      torque_prefetch<SP, G, STR>(in, sout, out_n, lane, tq);
+      torque_prefetch<SP, G, STR>(in, sout, out_n, lane, tq, Qplanes);
       asm volatile("" ::: "memory");  // (requested HERE: left alone, the compiler sinks these loads to their first use, behind the swing inputs)
     }
   }
@@ -842,7 +859,7 @@ QC_DEV void flush_out(const DevParams* __restrict__ Pg, const BatchIn& in, const
     store_from_stock<KIN, 4, SP, RLDS>(P, in, out, sout, lane, 0, RLDS ? Rplanes + lane : nullptr);
   }
   if constexpr (KIN) {
-    if (out.joint_tau) torque_pass<SP, RLDS, G, STR>(Pg, in, out, sout, out_n, lane, Rplanes, tq);
+    if (out.joint_tau) torque_pass<SP, RLDS, G, STR>(Pg, in, out, sout, out_n, lane, Rplanes, tq, Qplanes);
   }
 }
 
@@ -910,7 +927,10 @@ QC_DEV int repack_read(const DevParams* __restrict__ Pg, Lane4X& L4, Eqp4X& eqp4
 // the robots every other lane of the wave is waiting for).  Forking after ~6 recalculations still shortens the
 // slowest robot's chain: 20 -> 16 on config 3's 16 384 first robots, mean of the per-wave maximum 11.5 -> 10.6
 // (oracle/prototypes/proto_tail_fork.py); clamp-step variants add nothing at that point.
-template <bool KIN, bool UNIFORM, int SP, class LaneG>
+// HOLD (the joint_q one-lane kernel, whose re-pack records ALIAS the output stock - see QPARK in balance_kernel): no result is parked
+// before the last read of a record; the classic stage's finishers keep theirs in registers (three doubles and a few words per lane) until
+// the race stage is over.
+template <bool KIN, bool UNIFORM, int SP, bool HOLD = false, class LaneG>
 QC_DEV void finish_on_four_lanes(const DevParams* __restrict__ Pg, const LaneG& L, bool busy, unsigned long long bm, int slot, int member, int lane,
                                  double* __restrict__ sin, double* __restrict__ sout, const bool cold) {
   using Eqp4 = EqpDiagW<UNIFORM, 4, !QC_NO_STRIDED>;
@@ -922,7 +942,7 @@ QC_DEV void finish_on_four_lanes(const DevParams* __restrict__ Pg, const LaneG& 
   const int nb = __builtin_popcountll(bm) / GS;  // running robots
   if (nb == 0) return;
   QC_CLK_TAIL_BEGIN();
-  static_assert(16 * RS <= IN_PLANES * SP, "the re-pack records live in the idle input stock");
+  static_assert(16 * RS <= (HOLD ? OUT_PLANES : IN_PLANES) * SP, "the re-pack records live in the idle input stock (HOLD: under the output stock)");
   const int rank2 = __builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0)) / GS;
   __syncthreads();  // nobody reads the input stock any more
   if (busy) repack_write(L, sin + rank2 * RS, slot, member);
@@ -933,8 +953,10 @@ QC_DEV void finish_on_four_lanes(const DevParams* __restrict__ Pg, const LaneG& 
   const bool race = STR4 && cold && QC_PARAMS_HERE(Pg)->tail_race != 0;
   int nrun = nb;  // robots the race stage starts with (the first re-pack's records if the classic stage is skipped)
   QC_CLK_TAIL_LOOP();
+  Lane4 L4;
+  bool held = false;  // HOLD: this group's classic-stage result is still in L4
+  int slot_held = 0;
   if (!race || nb > 8) {
-    Lane4 L4;
     Eqp4 eqp4(nullptr);
     bool busy4 = g4 < nb;
     // groups beyond the running robots shadow record 0: the strided layout keeps every lane in the loop (MFMA)
@@ -958,10 +980,19 @@ QC_DEV void finish_on_four_lanes(const DevParams* __restrict__ Pg, const LaneG& 
     } else {
       while (busy4) busy4 = !L4.template iterate<Lane4::STEADY>(*QC_PARAMS_HERE(Pg), eqp4);
     }
-    if (g4 < nb && !busy4) L4.template push_result<SP>(sout, slot4);
+    if constexpr (HOLD) {
+      held = g4 < nb && !busy4;
+      slot_held = slot4;
+    } else {
+      if (g4 < nb && !busy4) L4.template push_result<SP>(sout, slot4);
+    }
     const unsigned run16 = (unsigned)(__builtin_amdgcn_ballot_w64(busy4) & 0xFFFFull);  // (member 0 of the strided groups = lanes 0-15)
     nrun = __builtin_popcount(run16);
     if (nrun == 0) {
+      if constexpr (HOLD) {
+        __syncthreads();  // every record has been read
+        if (held) L4.template push_result<SP>(sout, slot_held);
+      }
       QC_CLK_TAIL_END();
       return;
     }
@@ -1002,7 +1033,12 @@ QC_DEV void finish_on_four_lanes(const DevParams* __restrict__ Pg, const LaneG& 
     // the winner - the lower-numbered strategy if both got there in the same recalculation, strategy 0 with whatever
     // status it has if none did - parks the result
     const int win = solved_mask ? __builtin_ctz(solved_mask) : 0;
+    if constexpr (HOLD) __syncthreads();  // (the race stage's records have been read by every group)
     if (r < nrun && sid == win) LR.template push_result<SP>(sout, slotR);
+  }
+  if constexpr (HOLD) {
+    if constexpr (!STR4) __syncthreads();
+    if (held) L4.template push_result<SP>(sout, slot_held);
   }
 }
 
@@ -1071,8 +1107,11 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
   // once every robot of the wave is finished.
   constexpr bool HESS_ONLY = Eqp::kHessianInLds && MODE != 0;
   static_assert(!HESS_ONLY || (OUT_PLANES * SP + TASK_DOUBLES <= 78 * 64), "the output stock fits the Hessian planes it aliases");
+  // (see QPARK_* above: Rwb and the joint angles parked, the re-pack records under the output stock)
+  constexpr bool QPARK = KIN && G == 1 && MODE == 1 && !Eqp::kHessianInLds;
+  static_assert(!QPARK || SP == 65, "the QPARK layout is laid out for 64 slots");
   double* const sin = qc_lds;
-  double* const sout = HESS_ONLY ? qc_lds : qc_lds + IN_PLANES * SP;
+  double* const sout = HESS_ONLY ? qc_lds : qc_lds + (QPARK ? QPARK_OUT : IN_PLANES) * SP;
   // XCD-aware workgroup -> chunk map.  The dispatcher places workgroup b on XCD b % 8 (observed, MI355X_MICROARCH.md "Workgroup
   // dispatch"; a speed assumption only - any placement computes the same robots), each XCD with an L2 of its own.  A racing wave holds
   // 4 (or 8) robots: 288 contiguous bytes per 72-byte-row array, so neighbouring waves share the 128-byte lines their rows straddle,
@@ -1126,7 +1165,7 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
     constexpr bool DIRECT = G == 1;
     constexpr bool RPARK = DIRECT && !HESS_ONLY;  // Rwb parked in LDS for the output transform
     constexpr int R_PLANES = RPARK ? 9 : 0;
-    static_assert(!DIRECT || (R_PLANES * SP + 16 * REPACK_RS <= IN_PLANES * SP), "Rwb planes + re-pack records fit the input-stock area");
+    static_assert(!DIRECT || QPARK || (R_PLANES * SP + 16 * REPACK_RS <= IN_PLANES * SP), "Rwb planes + re-pack records fit the input-stock area");
     if constexpr (DIRECT) {
       const long left = end - cursor;
       stock_n = left < 64 ? (int)left : 64;
@@ -1152,6 +1191,10 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
         if constexpr (RPARK) {
 #pragma unroll
           for (int k = 0; k < 9; k++) sin[k * SP + lane] = S.R[k];
+        }
+        if constexpr (QPARK) {  // (fp = the twelve joint angles fetch_state read)
+#pragma unroll
+          for (int k = 0; k < 12; k++) sin[(QPARK_Q + k) * SP + lane] = fp[k];
         }
         L.load_direct(W, st, wv, robot, 0, P.tol_start);
       } else if constexpr (TWIN) {
@@ -1299,8 +1342,15 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
         if (busy) busy = !L.template iterate<LaneT::STEADY>(*QC_PARAMS_HERE(Pg), eqp);
         bm = __builtin_amdgcn_ballot_w64(busy);
       }
-      if (!busy && mine) L.template push_result<SP>(sout, grp);  // finished in the two-lane layout
-      finish_on_four_lanes<KIN, Eqp::kUniform, SP>(Pg, L, busy, bm, grp, member, lane, sin + R_PLANES * SP, sout, warm == nullptr);
+      if constexpr (QPARK) {
+        // the re-pack records live under the output stock: the tail parks its results after its last record read, and the robots that
+        // finished on the one-lane body after the tail (their results wait in this lane's registers)
+        finish_on_four_lanes<KIN, Eqp::kUniform, SP, true>(Pg, L, busy, bm, grp, member, lane, sout, sout, warm == nullptr);
+        if (!busy && mine) L.template push_result<SP>(sout, grp);
+      } else {
+        if (!busy && mine) L.template push_result<SP>(sout, grp);  // finished in the one- / two-lane layout
+        finish_on_four_lanes<KIN, Eqp::kUniform, SP>(Pg, L, busy, bm, grp, member, lane, sin + R_PLANES * SP, sout, warm == nullptr);
+      }
     } else if constexpr (TWIN) {
       // The one-lane dense form has no 4-lane tail (the exchange tile of the 4-lane dense body does not fit next to the Hessian
       // planes), so a wave walks its one-lane body until its slowest robot is done - at half the lanes or fewer busy for most of
@@ -1431,7 +1481,7 @@ __global__ __launch_bounds__(64, MIN_WAVES_PER_SIMD) void balance_kernel(const D
     }
     QC_CLK(7, 8);
     __syncthreads();
-    flush_out<Eqp::G, KIN, STR, SP, RPARK>(Pg, IN(), OUT(), sout, stock_n, lane, RPARK ? sin : nullptr);
+    flush_out<Eqp::G, KIN, STR, SP, RPARK>(Pg, IN(), OUT(), sout, stock_n, lane, RPARK ? sin : nullptr, QPARK ? sin + QPARK_Q * SP : nullptr);
     QC_CLK_END(8);
     return;
   }
@@ -1961,8 +2011,9 @@ static qc_pair_kernel_fn pair_kernel_for(int form) {
   return form == QC_FORM_UNIFORM ? (qc_pair_kernel_fn)balance_pair_kernel<EqpDiagW<true, 1>, false> : (qc_pair_kernel_fn)balance_pair_kernel<EqpDiagW<false, 1>, false>;
 #endif
 }
-static size_t lds_for(int form, int G, int mode) {
+static size_t lds_for(int form, int G, int mode, bool kin = false) {
   if (mode == 3) return 0;  // (static LDS: Rwb rows, record list, two counters)
+  if (kin && G == 1 && mode == 1 && form != QC_FORM_DENSE) return (size_t)qc::qpark_doubles() * sizeof(double);  // (balance_kernel: QPARK)
 
   const size_t stock = (size_t)qc::stock_doubles(qc::stock_slots(G, mode)) * sizeof(double);
   if (form == QC_FORM_DENSE && G != 4 && mode != 0) return (size_t)78 * 64 * sizeof(double);  // the Hessian planes alone (balance_kernel: HESS_ONLY)
@@ -1999,7 +2050,7 @@ static int plan_launch(qc_handle* h, long n, bool kin, bool warm, qc_launch_plan
   const int form = !h->diag_w ? QC_FORM_DENSE : (h->uniform ? QC_FORM_UNIFORM : QC_FORM_GENERAL);
   int G = 1;
   const long simds = (long)h->cus * 4;
-  const long cap4 = resident_workgroups(h, (const void*)kernel_for(form, 4, 1, kin, h->min_waves), lds_for(form, 4, 1)) * 16;
+  const long cap4 = resident_workgroups(h, (const void*)kernel_for(form, 4, 1, kin, h->min_waves), lds_for(form, 4, 1, kin)) * 16;
   if (form != QC_FORM_DENSE) {
     G = n <= 16 * simds ? 4 : (n <= 32 * simds ? 2 : 1);
     if (h->group_override) G = h->group_override;
@@ -2025,7 +2076,7 @@ static int plan_launch(qc_handle* h, long n, bool kin, bool warm, qc_launch_plan
   // waves' stragglers is mostly a longer chain at the end of the launch.  (Not the joint_q variants: they always run as
   // one-fill workgroups.)
   if (form != QC_FORM_DENSE && G == 1 && !kin && h->chunk_override <= 0 && h->one_fill_override != 0) {
-    const long res1 = resident_workgroups(h, (const void*)kernel_for(form, 1, 1, kin, h->min_waves), lds_for(form, 1, 1));
+    const long res1 = resident_workgroups(h, (const void*)kernel_for(form, 1, 1, kin, h->min_waves), lds_for(form, 1, 1, kin));
     bool use_pair = n >= 4 * res1 * 64;
     if (h->pair_override >= 0) use_pair = h->pair_override != 0;
     if (use_pair) {
@@ -2051,7 +2102,7 @@ static int plan_launch(qc_handle* h, long n, bool kin, bool warm, qc_launch_plan
   bool one_fill = false;
   long resident = 0;
   if (can_one_fill) {
-    resident = resident_workgroups(h, (const void*)kernel_for(form, G, 1, kin, h->min_waves), lds_for(form, G, 1));
+    resident = resident_workgroups(h, (const void*)kernel_for(form, G, 1, kin, h->min_waves), lds_for(form, G, 1, kin));
     // (round 5: the one-lane dense kernel too - with the Hessian planes as its only LDS it is resident once per SIMD and, as
     // one-fill workgroups, beats its persistent form at every size: 65 536 robots 138 vs 172 us, 262 144 317 vs 415,
     // profiles/r05_dense_sizes.log)
@@ -2091,7 +2142,7 @@ static int plan_launch(qc_handle* h, long n, bool kin, bool warm, qc_launch_plan
   }
   lp->fn = kernel_for(form, G, mode, kin, h->min_waves, race);
   lp->race = race;
-  lp->lds = lds_for(form, G, mode);
+  lp->lds = lds_for(form, G, mode, kin);
   lp->blocks = (unsigned)((n + chunk - 1) / chunk);
   lp->chunk = chunk;
   lp->refill_t = h->refill_t > 0 ? (h->refill_t + G - 1) / G : 1;
