@@ -1009,7 +1009,10 @@ def main():
             if "roofline_valu" in e:
                 o["issue"] = round(e["roofline_valu"]["issue_frac"], 3)
             return o
-        summary = {"sha": sha, "cfg2": {"n": n, "us": round(kernel_s * 1e6, 2), "QPs": float("%.4g" % line["value"]), "hbm": round(line["roofline"]["frac"], 4)} if cfg == 2 and not args.tick else None}
+        summary = {"sha": sha, "cfg2": {"n": n, "us": round(kernel_s * 1e6, 2), "QPs": float("%.4g" % line["value"]), "hbm": round(line["roofline"]["frac"], 4),
+                                        **({"x": round(line["roofline"]["traffic"] / line["roofline"]["bytes_per_launch"], 3)} if line["roofline"].get("traffic") else {}),
+                                        **({"issue": round(line["roofline_valu"]["issue_frac"], 3)} if "roofline_valu" in line else {})}
+                   if cfg == 2 and not args.tick else None}
         if "from_idle" in line:
             summary["cfg2_from_idle_QPs"] = float("%.4g" % line["from_idle"]["value"])
         for key, name in (("config3", "cfg3"), ("config4", "cfg4_warm"), ("config5_shard8", "cfg5_shard8"), ("config5_n1", "cfg5_n1"), ("dense_config2", "dense2"),
