@@ -189,7 +189,12 @@ def time_launches(launches, steps, warmup, dist=None, warm_all=False, warm_ms=0.
     ev1 = torch.cuda.Event(enable_timing=True)
     for i in range(w):
         launches[i % m]()
+    # (the instruments get their warm-up too: the first record / elapsed_time of a process - and of these two event objects - sets up
+    # the runtime's event machinery; left to the timed region that is 20-30 us of host time between its two clock reads, tools/r06_sync_latency.py)
+    ev0.record()
+    ev1.record()
     torch.cuda.synchronize()
+    ev0.elapsed_time(ev1)
     if warm_ms > 0.0:
         t_w = time.perf_counter()
         while (time.perf_counter() - t_w) * 1e3 < warm_ms:
