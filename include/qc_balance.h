@@ -256,7 +256,9 @@ int qc_query_launch(qc_handle* h, size_t n, int kin, int warm, qc_launch_info* o
  * "pair" (-1 heuristic, 0 never, 1 whenever one lane per robot on a 6x6 form: the paired-waves kernel, mode 3), "pair_th"
  * (its hand-over threshold, <= 32), "pair_refill" (free lane groups that trigger a refill, 1 ... 16), "pair_solo" (0: pairs in the last round of workgroups too),
  * "force_general" / "force_dense" (run the more general formulation on weights that would allow the
- * specialised one; same minimiser), "clamp_steps" (clamp steps a cold-started robot takes before its first ratio test in
+ * specialised one; same minimiser), "auto_dense" (1, default: a handle whose max diag(S) / min diag(W) exceeds 3e8 - regularisation
+ * weights 300 times further below S than the reference's - runs the dense 12x12 form although its W is diagonal, because the 6x6 dual
+ * forms lose digits that matter there, eps (S/w) |b|; 0: it keeps the 6x6 form), "clamp_steps" (clamp steps a cold-started robot takes before its first ratio test in
  * the one-fill kernels; 0 = the kernel's rule: five on one or two lanes per robot, one on four),
  * "tol_d" (relative multiplier tolerance), "polish" (1, default: the first time a robot would be accepted while its
  * smallest multiplier lies inside the noise band +-tol_d |grad|, that face is released once instead; 0: accept at -tol_d |grad|

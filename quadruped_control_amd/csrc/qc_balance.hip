@@ -1821,6 +1821,8 @@ struct qc_handle {
   bool uniform;  // additionally S diagonal and W = w*I -> scalar-constant specialisation
   // what qc_create was given: the tuning overrides (force_general / force_dense / max_iter / probe_batch_load) restore from these
   bool cfg_diag_w, cfg_uniform;
+  bool small_w;     // qc_create's rule: max diag(S) / min diag(W) above QC_DENSE_RATIO - the 6x6 dual forms lose digits that matter there
+  bool auto_dense;  // ... and such a handle runs the dense 12x12 form (qc_set_tuning "auto_dense", default on)
   int cfg_max_iter;
   bool force_general, force_dense, probing;
   // launch heuristics (defaults from measurements; qc_set_tuning overrides them)
@@ -1849,6 +1851,22 @@ struct qc_handle {
   int pair_refill;    // free lane groups that trigger a refill (0: heuristic)
   int pair_solo;      // 1: the last round of workgroups keeps each wave's stragglers in the wave (default), 0: pairs everywhere
 };
+
+// The 6x6 forms solve the DUAL system M = S^-1 + A~ B^-1 A~^T, whose B^-1 = O(1/w) part has rank = the number of free force
+// coordinates: with fewer than six of them free, M is a rank-k term of size 1/w on top of an S^-1 of order one and the forces
+// (1/w) A~^T v come out with an absolute error of eps (S/w) |b| - 1e-5 N at S/w = 1e9 (the parameter campaigns' 1.4e-5 ... 2.4e-5
+// at w ~ 1e-7, S ~ 100: profiles/r06_fuzz_campaigns.log), 1e-8 N at the reference's S/w = 1e6 (commander_node.cpp:305-307).  The
+// dense 12x12 form factorises the PRIMAL reduced Hessian, which is well-conditioned exactly there (tests/test_gpu_parity.py::
+// test_small_w_golden: < 5e-6 where the dual forms are at 2.4e-5), at three to five times the time.  Above this ratio a handle
+// therefore runs the dense form: accuracy before speed for regularisation weights this far below the reference's.
+#ifndef QC_DENSE_RATIO
+#define QC_DENSE_RATIO 3.0e8
+#endif
+// the formulation a handle runs, from what qc_create was given and the tuning flags - in one place, whatever the order of the calls
+static void resolve_form(qc_handle* h) {
+  h->diag_w = h->cfg_diag_w && !h->force_dense && !(h->small_w && h->auto_dense);
+  h->uniform = h->cfg_uniform && !h->force_general;
+}
 
 #define QC_COMMA(...) __VA_ARGS__
 static thread_local std::string g_err;
@@ -2296,10 +2314,17 @@ int qc_create_abi(const qc_params* p, int device, qc_handle** out, int abi_versi
       if (i != j && p->S[6 * i + j] != 0.0) uni = false;
   for (int i = 1; i < 12; i++)
     if (p->W[12 * i + i] != p->W[0]) uni = false;
-  h->uniform = uni;
   h->cfg_diag_w = diag;
   h->cfg_uniform = uni;
   h->force_general = h->force_dense = h->probing = false;
+  {
+    double smax = 0.0, wmin = p->W[0];
+    for (int i = 0; i < 6; i++) smax = std::fmax(smax, p->S[6 * i + i]);
+    for (int i = 1; i < 12; i++) wmin = std::fmin(wmin, p->W[12 * i + i]);
+    h->small_w = diag && smax > QC_DENSE_RATIO * wmin;
+    h->auto_dense = true;
+  }
+  resolve_form(h);
   for (int i = 0; i < 6; i++) d.Vd[i] = d.V[6 * i + i];
   d.w_u = p->W[0];
   d.inv_w_u = 1.0 / p->W[0];
@@ -2393,8 +2418,10 @@ int qc_set_tuning(qc_handle* h, const char* key, double value) {
     // general 6x6 form on uniform weights / dense 12x12 form on a diagonal W (same minimiser).  The form follows from what
     // qc_create was given and the two flags, in one place, whatever the order of the calls.
     (k == "force_general" ? h->force_general : h->force_dense) = value != 0;
-    h->diag_w = h->cfg_diag_w && !h->force_dense;
-    h->uniform = h->cfg_uniform && !h->force_general;
+    resolve_form(h);
+  } else if (k == "auto_dense") {  // 0: a diagonal W keeps its 6x6 form however small it is (QC_DENSE_RATIO above)
+    h->auto_dense = value != 0;
+    resolve_form(h);
   } else if (k == "tol_d") { h->dp.tol_d = value; h->dp.tol_start = h->dp.polish ? value : -value; params = true; }
   else if (k == "max_iter") {  // <= 0: back to the handle's own cap (qc_params.max_iter)
     if (value > (double)QC_MAX_ITER_LIMIT) return fail(QC_ERR_INVALID, "qc_set_tuning: max_iter must be <= 65535");

@@ -407,6 +407,29 @@ def test_pinv3_converges_on_an_exactly_rank_deficient_jacobian():
         np.testing.assert_allclose(Ap, ref, atol=1e-10 * max(1.0, np.abs(ref).max()))
 
 
+def test_c_oracle_against_the_small_w_golden_vectors():
+    """tests/golden/small_w_golden.json (numpy / NNLS restatement, w ~ 1e-7 - a hundredth of the reference's weight): the C oracle's primal
+    active-set solver is within 1e-6 of it on every vector (its own multiplier threshold leaves it 4.8e-7 away on campaign 555's trial 138)."""
+    import json
+
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "small_w_golden.json")))
+    assert len(gold["groups"]) == 4 and sum(len(g["cases"]) for g in gold["groups"]) == 20
+    fields = ("Rwb", "Rwb_d", "x", "xdot", "w", "x_d", "xdot_d", "w_d", "feet")
+    for grp in gold["groups"]:
+        import quadruped_control_amd as q
+
+        P = q.cheetah_params(0.6)
+        for k, v in grp["params"].items():
+            P[k] = np.array(v, dtype=np.float64) if isinstance(v, list) else v
+        assert P["W"][0][0] < 2.1e-7
+        b = {k: np.array([c[k] for c in grp["cases"]], dtype=np.float64) for k in fields}
+        b["stance"] = np.array([c["stance"] for c in grp["cases"]], dtype=np.uint8)
+        ref, st, _ = O.control_batch(P, b, threads=2)
+        exp = np.array([c["grf_body"] for c in grp["cases"]])
+        assert (st == 0).all()
+        assert np.max(np.abs(ref - exp) / np.maximum(1.0, np.abs(exp).max(axis=1, keepdims=True))) < 1e-6, grp["trial"]
+
+
 def test_pinv_band_takes_its_rank_from_the_device_rule():
     """inside the band where this build answers legJacobianInverse with the pseudo-inverse (|det| below
     max(epsilon, 64 epsilon (sum |l|)^3)) the DEVICE's pinv3_apply never takes a third pivot and drops a second one below 1e-9
