@@ -327,6 +327,33 @@ def test_bench_gpus_flag_is_not_ignored():
         assert r.returncode != 0 and "--gpus 2 but only" in (r.stderr + r.stdout)
 
 
+def test_bench_parses_rccl_transport_log():
+    """`ranks.rccl` of an N > 1 bench line is parsed from RCCL's own INIT / GRAPH log.  No multi-GPU box has ever run it, so
+    the parser is held here against lines in the format RCCL 2.26 prints (the one-rank log of the 1-GPU box has the INIT and Pattern lines;
+    the Channel / via lines follow NCCL's documented `Channel cc/n : a[dev] -> b[dev] [receive] via P2P/IPC[/read]` shape): eight ranks over
+    peer-to-peer links, a mixed P2P + SHM box, an empty log, and text it has never seen (kept verbatim, classified "unknown")."""
+    import bench
+
+    pre = "gpu-node:4242:4311 [3] NCCL INFO "
+    lines = [pre + "ncclCommInitRankConfig_impl comm 0x55d0 rank 3 nranks 8 cudaDev 3 nvmlDev 3 busId 9d000 commId 0x7a - Init START",
+             pre + "Pattern 4, crossNic 0, nChannels 28, bw 48.000000/48.000000, type XGMI/PIX, sameChannels 1",
+             pre + "Pattern 3, crossNic 0, nChannels 28, bw 48.000000/48.000000, type XGMI/PIX, sameChannels 1",
+             pre + "Ring 00 : 2 -> 3 -> 4", pre + "Tree 0 : -1 -> 3 -> 4/-1/-1"]
+    for c in range(28):
+        lines.append(pre + "Channel %02d/0 : 3[3] -> 4[4] via P2P/IPC" % c)
+        lines.append(pre + "Channel %02d/0 : 2[2] -> 3[3] [receive] via P2P/IPC/read" % c)
+    lines.append(pre + "Connected all rings")
+    r = bench.parse_rccl_log("\n".join(lines), 8)
+    assert r["nranks"] == 8 and r["channels"] == 28 and r["via"] == {"P2P/IPC": 28, "P2P/IPC/read": 28}
+    assert r["transport"] == "P2P (xGMI / peer access)" and r["graph"]["pattern4"] == {"nChannels": 28, "bw": 48.0, "type": "XGMI/PIX"}
+    assert any("nranks 8" in l for l in r["lines"]) and any("via P2P/IPC" in l for l in r["lines"]) and len(r["lines"]) <= 24
+    mixed = bench.parse_rccl_log("\n".join(lines + [pre + "Channel 00/0 : 3[3] -> 0[0] via SHM/direct/direct"]), 8)
+    assert mixed["transport"] == "P2P/IPC+P2P/IPC/read+SHM/direct/direct" and mixed["via"]["SHM/direct/direct"] == 1
+    assert bench.parse_rccl_log("", 8)["transport"] == "unknown (no channel lines in the log)" and bench.parse_rccl_log("", 1)["transport"] == "none (one rank)"
+    odd = bench.parse_rccl_log(pre + "comm 0x1 rank 0 nranks 2 something new\n" + pre + "links are XGMI today", 2)
+    assert odd["nranks"] == 2 and odd["channels"] is None and len(odd["lines"]) == 2 and odd["transport"].startswith("unknown")
+
+
 def test_device_generator_matches_the_host_generator_on_cpu():
     """workloads_device (torch int64 splitmix64) against workloads (numpy uint64): the uniforms and everything decided
     by them (gait kind, phases, contact states) bit-identical, the rotation matrices / foot positions to the last ulp."""
